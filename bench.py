@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the ROMP inference hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of synthetic images PER GPU
+(BASELINE.json configs[1]: ROMP HRNet-32, 512x512, batch 32):  network (323 fused layer
+kernels) -> center-map parse -> SMPL meshes for every detection -> (N>1: RCCL all-gather of the
+per-person records over xGMI).  Inputs are resident in HBM when the timed region starts.
+Weights are seeded synthetic tensors of the reference's shapes (the licensed ROMP.pkl /
+SMPL_NEUTRAL.pth cannot be shipped); arithmetic is float32 end to end.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).  After the timed
+region rank 0 additionally measures (a) the per-kernel-class roofline with HIP events on the
+launch stream and (b) the CPU baseline (the oracle restatement of the reference, timed on the
+host cores of this box on a bounded sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--center-thresh', type=float, default=1.3)
+    ap.add_argument('--graph', type=int, default=0, help='replay the network from a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--with-verts', type=int, default=0, help='N>1: also all-gather the 6890x3 vertices')
+    return ap.parse_args()
+
+
+def roofline_report(model, images, lib, L):
+    """Per kernel variant: sum of algorithmic FLOPs / bytes over its launches / sum of HIP-event
+    durations (events recorded on the launch stream around every layer kernel)."""
+    net = model.model
+    B = images.shape[0]
+    ms = net.profile(images, iters=3)
+    buf = C.create_string_buffer(128)
+    agg = {}
+    for op, t, fl, by in zip(net.program.ops, ms, net.program.flops, net.program.bytes):
+        L.check(lib.romp_conv_describe(C.byref(op), B, buf, 128))
+        a = agg.setdefault(buf.value.decode(), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a['ms'] += t; a['flops'] += fl * B; a['bytes'] += by * B; a['launches'] += 1
+    classes = {}
+    for k, a in agg.items():
+        classes[k] = dict(launches=a['launches'], ms=round(a['ms'], 4),
+                          tflops=round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2) if a['ms'] > 0 else 0.0,
+                          gbs=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1) if a['ms'] > 0 else 0.0)
+    dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+    name, a = dom
+    achieved = a['flops'] / (a['ms'] * 1e-3) / 1e12
+    roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                launches=a['launches'], avg_launch_ms=round(a['ms'] / a['launches'], 5),
+                flops_per_launch=a['flops'] / a['launches'], alg_bytes_per_launch=a['bytes'] / a['launches'],
+                hbm_gbs=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1), hbm_frac=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                net_ms_per_batch=round(sum(ms), 3))
+    return roof, classes
+
+
+def cpu_baseline(sd, smpl_model, thresh, seconds):
+    """The oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
+    from oracle import romp_oracle as O
+    from romp_amd import synthetic as S
+    torch.set_num_threads(os.cpu_count())
+    Bc = 4
+    img = S.make_images(Bc, seed=1)
+
+    def step():
+        cm, pm = O.romp_net_forward(sd, img)
+        r = O.parsing_outputs(cm.numpy(), pm.numpy(), thresh)
+        if r is not None:
+            O.smpl_forward(smpl_model, r['smpl_betas'], r['smpl_thetas'])
+    step()
+    t0, n = time.time(), 0
+    while True:
+        step(); n += 1
+        if time.time() - t0 > seconds or n >= 8:
+            break
+    dt = time.time() - t0
+    return dict(value=round(Bc * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload, torch-CPU float32 '
+                       '(reference onnxruntime path unavailable: module not installed)' % (n, Bc))
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus, 'launch with --nproc-per-node == --gpus'
+
+    import romp_amd
+    from romp_amd import lib as L, synthetic as S, distributed as D
+    lib = L.load()
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
+    sd = S.make_romp_state_dict(0)
+    smpl_model = S.make_smpl_model(0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+    if args.graph:
+        model.model.set_graph(True)
+    B = args.batch
+    lo, hi = D.shard_range(B * world, rank, world)            # weak scaling: B images per GPU
+    images = S.make_images(B, seed=1 + rank, device=dev)
+    stream = torch.cuda.Stream(dev)
+    persons = 0
+
+    def step():
+        nonlocal persons
+        if world > 1:
+            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts))
+            persons = sum(counts)
+        else:
+            out, bids = model.forward_batch(images)
+            persons = 0 if out is None else out['cam'].shape[0]
+        return out
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_images = B * world * args.steps
+    result = {
+        'metric': 'images/sec (512x512, HRNet-32)', 'value': round(total_images / dt, 2), 'unit': 'images/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); '
+                               'net+parse+SMPL%s' % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
+                   'batch_per_gpu': B, 'global_batch': B * world, 'persons_per_image': round(persons / (B * world), 2),
+                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'parallelism': 'dp%d' % world},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            with torch.cuda.stream(stream):
+                roof, classes = roofline_report(model, images, lib, L)
+            result['roofline'] = roof
+            result['kernel_classes'] = classes
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(sd, smpl_model, args.center_thresh, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,154 @@
+/* romp_hip.h -- C ABI of libromp_hip.so, the MI355X (gfx950) implementation of the ROMP
+ * inference hot path.
+ *
+ * Drop-in seams (reference = Arthur151/ROMP, simple_romp/romp):
+ *   seam #1  network      ROMPv1.forward                    model.py:470-481
+ *                         (the reference already abstracts it as an ONNX session,
+ *                          main.py:109: image (B,512,512,3) -> center_maps, params_maps)
+ *   seam #2  parsing      parsing_outputs / CenterMap       post_parser.py:27-47,135-146
+ *                         + 1.1**scale (main.py:113) + rot6D->axis-angle (utils.py:471-682)
+ *   seam #3  SMPL         SMPL.forward / lbs                smpl.py:62-108,111-290
+ *   seam #4  projection   batch_orth_proj + to-original-image   utils.py:309-315,
+ *                         post_parser.py:81-88, convert_cam_to_3d_trans utils.py:303-307
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - memory is owned by the caller (PyTorch-ROCm tensors); contexts keep their own packed
+ *     copies of constants and never free caller memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued on it, nothing synchronises unless stated;
+ *   - every entry point returns 0 on success or a negative ROMP_E* code; the message for
+ *     the calling thread is available from romp_last_error().  No exceptions, no exit().
+ *   - contexts are not thread-safe (one per device/stream, like the reference's one module
+ *     per process).
+ */
+#ifndef ROMP_HIP_H
+#define ROMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROMP_OK          0
+#define ROMP_EINVAL     -1   /* bad argument / unsupported shape            */
+#define ROMP_EHIP       -2   /* a HIP runtime call failed                   */
+#define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
+#define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
+
+#define ROMP_ABI_VERSION 1
+
+int         romp_abi_version(void);
+const char* romp_last_error(void);
+
+/* ------------------------------------------------------------------ seam #1: network */
+
+/* One step of the layer program.  The host (romp_amd/plan.py) lowers the model definition
+ * (HRNet-32 + ROMP head: model.py:246-481) into this flat list; the executor runs it.
+ * Activations are NHWC float32; `*_buf` are indices into the context's activation arena,
+ * or one of the ROMP_BUF_* pseudo buffers. */
+#define ROMP_BUF_NONE    (-1)
+#define ROMP_BUF_IMAGE   (-2)   /* forward()'s image argument  (B,512,512,3) 0..255      */
+#define ROMP_BUF_CENTER  (-3)   /* forward()'s center_maps out (B,64,64)                  */
+#define ROMP_BUF_PARAMS  (-4)   /* forward()'s params_maps out (B,64,64,145) NHWC         */
+
+#define ROMP_OP_STEM      1     /* x/255*2-1 + conv3x3 s2 (Cin=3) + BN + ReLU  (model.py:384-387) */
+#define ROMP_OP_CONV      2     /* conv KxK (K=1|3, stride 1|2) + scale/shift (+res) (+ReLU)      */
+#define ROMP_OP_FUSESUM   3     /* y = relu(sum_t up_nearest(T_t))   (model.py:233-244)           */
+
+typedef struct romp_op {
+    int32_t kind;
+    int32_t in_buf, out_buf, res_buf;
+    int32_t H, W;                 /* input spatial size                                   */
+    int32_t Cin, Cout;            /* per group                                            */
+    int32_t ksize, stride, relu;
+    int32_t groups;               /* >1: independent convs sharing one launch (head towers)*/
+    int32_t in_cstride, in_coff, in_gstride;     /* channel stride / offset / per-group offset */
+    int32_t out_cstride, out_coff, out_gstride;
+    int32_t res_cstride, res_coff, res_gstride;
+    int32_t cin_pad, cout_pad;    /* padded dims of the packed weight (see plan.py)       */
+    int32_t n_terms;              /* FUSESUM: number of terms (<=4)                       */
+    int32_t term_buf[4];
+    int32_t term_shift[4];        /* log2 of the nearest-upsample factor of each term     */
+    int32_t term_cstride[4];
+    const float* weight;          /* packed [group][chunk][tap][cin/4][cout_pad][4]       */
+    const float* scale;           /* [group][cout_pad]  gamma/sqrt(var+eps)  (or 1)       */
+    const float* shift;           /* [group][cout_pad]  beta-mean*scale (+scale*bias)     */
+} romp_op;
+
+typedef struct romp_net romp_net;
+
+/* buf_floats_per_image[i] = size of arena buffer i for ONE image, in floats. */
+int  romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops,
+                     const int64_t* buf_floats_per_image_host, int n_bufs, int max_batch);
+/* image (B,512,512,3) float 0..255 -> center_maps (B,64,64), params_maps (B,64,64,145).
+ * Replaces ort_session.run / self.model(...) at main.py:109-112. */
+int  romp_net_forward(romp_net* net, const float* image_nhwc, int B,
+                      float* center_maps, float* params_maps_nhwc, void* stream);
+/* Debug/inspection: copy arena buffer `buf` (B images) to `dst` (device). */
+int  romp_net_read_buffer(romp_net* net, int buf, int B, float* dst, int64_t n_floats, void* stream);
+/* Initialise arena buffer `buf` (all max_batch images) from `src` (device); used once for the
+ * constant CoordConv channels of the head input (model.py:473). */
+int  romp_net_write_buffer(romp_net* net, int buf, const float* src, int64_t n_floats, void* stream);
+/* 0: tuned MFMA kernels (default)   1: naive direct-conv kernels (bring-up cross-check) */
+int  romp_net_set_mode(romp_net* net, int mode);
+/* 1: capture the layer program into a hipGraph per (B, pointers) and replay it. */
+int  romp_net_set_graph(romp_net* net, int enable);
+/* Time the most recent forward per op (HIP events on `stream`); ms_out_host[n_ops]. */
+int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,
+                      float* params_maps_nhwc, void* stream, float* ms_out_host, int iters);
+void romp_net_destroy(romp_net* net);
+
+/* Stand-alone conv launcher (tests / microbenchmarks of one layer). */
+int  romp_conv_forward(const romp_op* op_host, const float* in, const float* res, float* out,
+                       int B, int mode, void* stream);
+
+/* Name of the kernel variant the dispatcher picks for `op` at batch B (profiling reports). */
+int  romp_conv_describe(const romp_op* op_host, int B, char* out_host, int n);
+
+/* ------------------------------------------------------------------ seam #2: parsing */
+
+/* parsing_outputs (post_parser.py:135-146) on device.  Capacity-bounded: row arrays hold
+ * B*max_person rows; *count_host receives N (this call synchronises the stream once, like
+ * the reference's torch.where at post_parser.py:45).  Rows are batch-major and
+ * score-descending inside an image; ties broken by lower flat index.
+ *   center_maps (B,64,64)      params_maps (B,64,64,145) NHWC, scale channel NOT yet 1.1**
+ *   batch_ids/flat_inds int32 (N)   scores (N)   params_pred (N,145) (scale already 1.1**s)
+ *   cam (N,3)  thetas (N,72)  betas (N,10)  center_preds int32 (N,2)  */
+int  romp_parse(const float* center_maps, const float* params_maps_nhwc, int B,
+                float conf_thresh, int max_person, int32_t* count_host,
+                int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+                float* cam, float* thetas, float* betas, int32_t* center_preds,
+                int32_t* workspace /* B*(2*max_person+2) int32 */, void* stream);
+/* rot6D_to_angular (utils.py:471-475): x6 (n,6) -> aa (n,3) */
+int  romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream);
+
+/* ------------------------------------------------------------------ seam #3: SMPL */
+
+typedef struct smpl_ctx smpl_ctx;
+/* Built from the tensors of the packed SMPL file (schema: pack_smpl_info.py:70-111).
+ * parents_host: 24 int64 (kintree_table), extra_idx_host: 21 int64. */
+int  smpl_ctx_create(smpl_ctx** out, const float* v_template, const float* shapedirs, int n_betas,
+                     const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                     const int64_t* parents_host, const float* J_regressor_extra9,
+                     const float* J_regressor_h36m17, const int64_t* extra_idx_host,
+                     int max_persons, void* stream);
+/* SMPL.forward (smpl.py:62-108): betas (N,n_betas), thetas (N,72) ->
+ * verts (N,6890,3), joints (N,71,3). */
+int  smpl_forward(smpl_ctx* ctx, const float* betas, int n_betas, const float* thetas, int N,
+                  int root_align, float* verts, float* joints, void* stream);
+void smpl_ctx_destroy(smpl_ctx* ctx);
+
+/* ------------------------------------------------------------------ seam #4: projection */
+
+/* batch_orth_proj + convert_proejection_from_input_to_orgimg + convert_cam_to_3d_trans.
+ * joints (N,J,3), cam (N,3), pad_info_host[6] = top,bottom,left,right,h,w  ->
+ * pj2d (N,J,2) normalised, pj2d_org (N,J,2) original-image pixels, cam_trans (N,3). */
+int  romp_project(const float* joints, int N, int J, const float* cam, const float* pad_info_host,
+                  float* pj2d, float* pj2d_org, float* cam_trans, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMP_HIP_H */

@@ -111,10 +111,12 @@ def romp_param_spec():
     return sh
 
 
-def make_romp_state_dict(seed=0):
+def make_romp_state_dict(seed=0, center_bias=0.0):
     """Deterministic synthetic ROMPv1 weights (the licensed ROMP.pkl is unavailable here).
     conv/bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)); every BatchNorm gets non-trivial
-    statistics so that BN folding is exercised (SURVEY.md §8d recipe)."""
+    statistics so that BN folding is exercised (SURVEY.md §8d recipe).  `center_bias` is added
+    to the center head's output bias so that synthetic center maps become positive and a
+    positive threshold selects a few persons per image."""
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for k, (shp, kind) in romp_param_spec().items():
@@ -132,6 +134,8 @@ def make_romp_state_dict(seed=0):
         else:                                               # conv bias (head convs)
             v = (torch.rand(shp, generator=g) * 2 - 1) * 0.05
         sd[k] = v.float().contiguous()
+    if center_bias:
+        sd['final_layers.2.2.bias'] = sd['final_layers.2.2.bias'] + float(center_bias)
     return sd
 
 

@@ -1,0 +1,40 @@
+// common.h -- shared helpers for libromp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/romp_hip.h"
+
+namespace romp {
+
+void set_error(const char* fmt, ...);
+
+#define ROMP_HIP_CHECK(expr)                                                          \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            romp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                            __FILE__, __LINE__);                                      \
+            return ROMP_EHIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+#define ROMP_REQUIRE(cond, ...)                                                       \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            romp::set_error(__VA_ARGS__);                                             \
+            return ROMP_EINVAL;                                                       \
+        }                                                                             \
+    } while (0)
+
+// launchers implemented in the kernel translation units
+int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B,
+                int mode, hipStream_t st);
+int describe_conv(const romp_op& op, int B, char* out, int n);
+int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
+struct FuseTerm { const float* ptr; int shift; int cstride; };
+int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
+                   int out_cstride, int out_coff, int relu, hipStream_t st);
+
+}  // namespace romp

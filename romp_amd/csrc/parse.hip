@@ -1,0 +1,245 @@
+// parse.hip -- center-map parsing and parameter packing (seam #2) + projection (seam #4).
+//
+// Reference: CenterMap.parse_centermap / nms / gather_feature (post_parser.py:27-64),
+// parameter_sampling + pack_params_dict + parsing_outputs (post_parser.py:66-79,128-146),
+// params_maps[:,0] = 1.1**params_maps[:,0] (main.py:113),
+// rot6D_to_angular -> rot6d_to_rotmat -> rotation_matrix_to_quaternion -> quaternion_to_angle_axis
+// (utils.py:471-491, 535-682), batch_orth_proj (utils.py:309-315),
+// convert_proejection_from_input_to_orgimg (post_parser.py:81-88), convert_cam_to_3d_trans
+// (utils.py:303-307).
+//
+// The reference runs ~12 small kernels + a host sync for the parse, a full (B,145,64,64) transpose
+// copy to sample N rows, and ~60 elementwise kernels for the rotation conversion.  Here: one
+// workgroup per image does the 5x5 max-NMS, threshold and ordered top-K out of LDS; one wave per
+// detection gathers its 580-byte NHWC parameter row (contiguous -- no transpose) and converts the
+// 22 rotations.  Everything is latency-bound; bytes moved = 16 KB + N_b*580 B per image.
+#include "common.h"
+#include <vector>
+
+#pragma clang fp contract(off)   // keep the reference's rounding in the ill-conditioned branches
+
+namespace romp {
+
+constexpr int MAP = 64, NPIX = MAP * MAP;
+
+// ws layout per image: [max_person] flat index, [max_person] score bits, [1] count, [1] total candidates
+__global__ __launch_bounds__(256) void parse_nms_topk_kernel(const float* __restrict__ center, float thresh,
+                                                              int max_person, int32_t* __restrict__ ws) {
+    __shared__ float s_map[NPIX];
+    __shared__ float s_score[NPIX];
+    __shared__ int s_idx[NPIX];
+    __shared__ int s_count;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* cm = center + (size_t)b * NPIX;
+    for (int p = tid; p < NPIX; p += 256) s_map[p] = cm[p];
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int p = tid; p < NPIX; p += 256) {
+        const int y = p / MAP, x = p % MAP;
+        const float v = s_map[p];
+        float m = v;                                   // MaxPool2d(5,1,2): implicit -inf padding
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)MAP) continue;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)MAP) continue;
+                m = fmaxf(m, s_map[yy * MAP + xx]);
+            }
+        }
+        const float score = (m == v) ? v : v * 0.0f;   // det * (maxm == det).float()
+        if (score > thresh) {
+            const int slot = atomicAdd(&s_count, 1);
+            s_score[slot] = score;
+            s_idx[slot] = p;
+        }
+    }
+    __syncthreads();
+    const int n = s_count;
+    int32_t* w = ws + (size_t)b * (2 * max_person + 2);
+    for (int c = tid; c < n; c += 256) {
+        const float sc = s_score[c];
+        const int id = s_idx[c];
+        int rank = 0;
+        for (int k = 0; k < n; ++k) {
+            const float so = s_score[k];
+            rank += (so > sc) || (so == sc && s_idx[k] < id);
+        }
+        if (rank < max_person) {
+            w[rank] = id;
+            w[max_person + rank] = __float_as_int(sc);
+        }
+    }
+    if (tid == 0) {
+        w[2 * max_person] = n < max_person ? n : max_person;
+        w[2 * max_person + 1] = n;
+    }
+}
+
+__device__ __forceinline__ void rot6d_to_aa_dev(const float* x, float* aa) {
+    // rot6d_to_rotmat (utils.py:477-491): x.view(3,2): a1 = x[0],x[2],x[4]; a2 = x[1],x[3],x[5]
+    const float a1x = x[0], a1y = x[2], a1z = x[4], a2x = x[1], a2y = x[3], a2z = x[5];
+    float n1 = sqrtf(a1x * a1x + a1y * a1y + a1z * a1z);
+    n1 = fmaxf(n1, 1e-6f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float dot = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float ux = a2x - dot * b1x, uy = a2y - dot * b1y, uz = a2z - dot * b1z;
+    float n2 = sqrtf(ux * ux + uy * uy + uz * uz);
+    n2 = fmaxf(n2, 1e-6f);
+    const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+    // R[r][c]: columns b1,b2,b3.  rmat_t = R^T, m(i,j) = R[j][i]  (utils.py:636)
+    const float m00 = b1x, m01 = b1y, m02 = b1z;      // m(0,j) = R[j][0] = b1[j]
+    const float m10 = b2x, m11 = b2y, m12 = b2z;
+    const float m20 = b3x, m21 = b3y, m22 = b3z;
+    const bool d2 = m22 < 1e-6f, d01 = m00 > m11, d0n1 = m00 < -m11;
+    float q0, q1, q2, q3, t;
+    if (d2 && d01) {
+        t = 1 + m00 - m11 - m22;
+        q0 = m12 - m21; q1 = t; q2 = m01 + m10; q3 = m20 + m02;
+    } else if (d2 && !d01) {
+        t = 1 - m00 + m11 - m22;
+        q0 = m20 - m02; q1 = m01 + m10; q2 = t; q3 = m12 + m21;
+    } else if (!d2 && d0n1) {
+        t = 1 - m00 - m11 + m22;
+        q0 = m01 - m10; q1 = m20 + m02; q2 = m12 + m21; q3 = t;
+    } else {
+        t = 1 + m00 + m11 + m22;
+        q0 = t; q1 = m12 - m21; q2 = m20 - m02; q3 = m01 - m10;
+    }
+    const float st = sqrtf(t);
+    q0 = q0 / st * 0.5f; q1 = q1 / st * 0.5f; q2 = q2 / st * 0.5f; q3 = q3 / st * 0.5f;
+    // quaternion_to_angle_axis (utils.py:554-604)
+    const float s2 = q1 * q1 + q2 * q2 + q3 * q3;
+    const float s = sqrtf(s2);
+    const float two_theta = 2.0f * (q0 < 0.0f ? atan2f(-s, -q0) : atan2f(s, q0));
+    const float k = s2 > 0.0f ? two_theta / s : 2.0f;
+    float rx = q1 * k, ry = q2 * k, rz = q3 * k;
+    aa[0] = (rx != rx) ? 0.f : rx;                     // aa[isnan(aa)] = 0 (utils.py:551)
+    aa[1] = (ry != ry) ? 0.f : ry;
+    aa[2] = (rz != rz) ? 0.f : rz;
+}
+
+__global__ __launch_bounds__(64) void parse_pack_kernel(
+    const float* __restrict__ center, const float* __restrict__ params, int B, int max_person,
+    const int32_t* __restrict__ ws, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+    float* cam, float* thetas, float* betas, int32_t* center_preds) {
+    const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int stride = 2 * max_person + 2;
+    const int cnt = ws[(size_t)b * stride + 2 * max_person];
+    if (r >= cnt) return;
+    int off = 0;
+    for (int k = lane; k < b; k += 64) off += ws[(size_t)k * stride + 2 * max_person];
+    for (int d = 32; d > 0; d >>= 1) off += __shfl_xor(off, d);
+    const int row = off + r;
+    const int flat = ws[(size_t)b * stride + r];
+    const float sc = __int_as_float(ws[(size_t)b * stride + max_person + r]);
+    __shared__ float s_p[148];
+    const float* src = params + ((size_t)b * NPIX + flat) * 145;
+    for (int c = lane; c < 145; c += 64) {
+        float v = src[c];
+        if (c == 0) v = powf(1.1f, v);                 // main.py:113
+        s_p[c] = v;
+        params_pred[(size_t)row * 145 + c] = v;
+    }
+    __syncthreads();
+    if (lane < 3) cam[row * 3 + lane] = s_p[lane];
+    if (lane < 10) betas[row * 10 + lane] = s_p[135 + lane];
+    if (lane < 22) {
+        float aa[3];
+        rot6d_to_aa_dev(s_p + 3 + lane * 6, aa);       // joint 0 = global_orient, 1..21 = body_pose
+        thetas[row * 72 + lane * 3 + 0] = aa[0];
+        thetas[row * 72 + lane * 3 + 1] = aa[1];
+        thetas[row * 72 + lane * 3 + 2] = aa[2];
+    } else if (lane < 28) {
+        thetas[row * 72 + 66 + (lane - 22)] = 0.f;     // two hand joints padded with zeros (post_parser.py:76)
+    }
+    if (lane == 0) {
+        batch_ids[row] = b;
+        flat_inds[row] = flat;
+        scores[row] = sc;                              // == center_confs (post_parser.py:145)
+        center_preds[row * 2 + 0] = (flat % MAP) * 512 / 64;
+        center_preds[row * 2 + 1] = (flat / MAP) * 512 / 64;
+    }
+}
+
+__global__ void rot6d_kernel(const float* __restrict__ x6, int n, float* __restrict__ aa) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[6], o[3];
+    for (int k = 0; k < 6; ++k) x[k] = x6[(size_t)i * 6 + k];
+    rot6d_to_aa_dev(x, o);
+    for (int k = 0; k < 3; ++k) aa[(size_t)i * 3 + k] = o[k];
+}
+
+__global__ void project_kernel(const float* __restrict__ joints, int N, int J, const float* __restrict__ cam,
+                               float pad_size, float left, float top, float* pj2d, float* pj2d_org,
+                               float* cam_trans) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * J) {
+        const int n = i / J;
+        const float s = cam[n * 3], tx = cam[n * 3 + 1], ty = cam[n * 3 + 2];
+        const float px = joints[(size_t)i * 3] * s + tx, py = joints[(size_t)i * 3 + 1] * s + ty;
+        pj2d[(size_t)i * 2] = px; pj2d[(size_t)i * 2 + 1] = py;
+        pj2d_org[(size_t)i * 2] = (px + 1.f) * pad_size / 2.f - left;
+        pj2d_org[(size_t)i * 2 + 1] = (py + 1.f) * pad_size / 2.f - top;
+    }
+    if (i < N) {
+        const float s = cam[i * 3], tx = cam[i * 3 + 1], ty = cam[i * 3 + 2];
+        cam_trans[i * 3 + 0] = (tx / s) * 2.f;
+        cam_trans[i * 3 + 1] = (ty / s) * 2.f;
+        cam_trans[i * 3 + 2] = (1.f / s) * 2.f;
+    }
+}
+
+}  // namespace romp
+
+using namespace romp;
+
+extern "C" {
+
+int romp_parse(const float* center_maps, const float* params_maps, int B, float conf_thresh, int max_person,
+               int32_t* count_host, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+               float* cam, float* thetas, float* betas, int32_t* center_preds, int32_t* workspace, void* stream) {
+    ROMP_REQUIRE(center_maps && params_maps && count_host && workspace && B > 0, "romp_parse: bad arguments");
+    ROMP_REQUIRE(max_person >= 1 && max_person <= 1024, "romp_parse: max_person %d out of range", max_person);
+    ROMP_REQUIRE(batch_ids && flat_inds && scores && params_pred && cam && thetas && betas && center_preds,
+                 "romp_parse: null output");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(parse_nms_topk_kernel, dim3(B), dim3(256), 0, st, center_maps, conf_thresh, max_person, workspace);
+    ROMP_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(parse_pack_kernel, dim3(max_person, B), dim3(64), 0, st, center_maps, params_maps, B, max_person,
+                       workspace, batch_ids, flat_inds, scores, params_pred, cam, thetas, betas, center_preds);
+    ROMP_HIP_CHECK(hipGetLastError());
+    std::vector<int32_t> cnt((size_t)B * (2 * max_person + 2));
+    ROMP_HIP_CHECK(hipMemcpyAsync(cnt.data(), workspace, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ROMP_HIP_CHECK(hipStreamSynchronize(st));
+    int total = 0;
+    for (int b = 0; b < B; ++b) total += cnt[(size_t)b * (2 * max_person + 2) + 2 * max_person];
+    *count_host = total;
+    return ROMP_OK;
+}
+
+int romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream) {
+    ROMP_REQUIRE(x6 && aa && n >= 0, "romp_rot6d_to_aa: bad arguments");
+    if (n == 0) return ROMP_OK;
+    hipLaunchKernelGGL(rot6d_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, x6, n, aa);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+int romp_project(const float* joints, int N, int J, const float* cam, const float* pad_info_host, float* pj2d,
+                 float* pj2d_org, float* cam_trans, void* stream) {
+    ROMP_REQUIRE(joints && cam && pad_info_host && pj2d && pj2d_org && cam_trans && N >= 0 && J > 0,
+                 "romp_project: bad arguments");
+    if (N == 0) return ROMP_OK;
+    const float top = pad_info_host[0], left = pad_info_host[2], h = pad_info_host[4], w = pad_info_host[5];
+    const float pad_size = h > w ? h : w;
+    const int total = N * J;
+    hipLaunchKernelGGL(project_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, joints, N, J, cam,
+                       pad_size, left, top, pj2d, pj2d_org, cam_trans);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// stem_fuse.hip -- the two non-GEMM layer kernels of the network:
+//   * stem conv1: input normalisation x/255*2-1 (model.py:384) fused into the 3->64 3x3 stride-2
+//     convolution + BN + ReLU (model.py:385-387).  K = 27 is too thin for the matrix cores and the
+//     layer is bound by its 16.8 MB/image output, so it is a VALU kernel whose stores are laid out
+//     for 1 KiB contiguous runs (4 adjacent pixels x 64 channels per store instruction).
+//   * fuse-sum: y_i = relu(sum_j up_nearest(T_j))  (HighResolutionModule.forward model.py:233-244)
+//     -- replaces the reference's nearest-upsample kernels and the chain of adds with one pass that
+//     reads each term once and writes y once.  Summation order is the reference's (j ascending).
+#include "common.h"
+
+namespace romp {
+
+struct StemParams {
+    const float* image; const float* w; const float* scale; const float* shift; float* out;
+    int H, W, Ho, Wo, out_cs, out_co, tiles_x, tiles_y;
+};
+
+// packed stem weight: [tap 9][cin 3][cout 64]
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
+    constexpr int T = 16, HS = 2 * T + 1;           // 16x16 output tile, 33x33 input halo
+    __shared__ __attribute__((aligned(16))) float s_in[HS * HS * 3];
+    __shared__ __attribute__((aligned(16))) float s_w[27 * 64];
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x; bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const float* img = p.image + (size_t)b * p.H * p.W * 3;
+    const int iy0 = ty * T * 2 - 1, ix0 = tx * T * 2 - 1;
+    for (int idx = tid; idx < HS * HS * 3; idx += 256) {
+        const int e = idx % (HS * 3), hy = idx / (HS * 3);
+        const int iy = iy0 + hy, ix = ix0 + e / 3;
+        float v = 0.f;                               // zero padding is applied AFTER normalisation
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            v = (img[((size_t)iy * p.W + ix0) * 3 + e] / 255.0f) * 2.0f - 1.0f;
+        s_in[idx] = v;
+    }
+    for (int idx = tid; idx < 27 * 64; idx += 256) s_w[idx] = p.w[idx];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cg = lane & 15, ps = lane >> 4;
+    float4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const float4 w4 = *reinterpret_cast<const float4*>(s_w + (tap * 3 + ci) * 64 + cg * 4);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = wave * 4 + (t >> 2), col = (t & 3) * 4 + ps;
+                const float x = s_in[((row * 2 + dy) * HS + col * 2 + dx) * 3 + ci];
+                acc[t].x = fmaf(x, w4.x, acc[t].x); acc[t].y = fmaf(x, w4.y, acc[t].y);
+                acc[t].z = fmaf(x, w4.z, acc[t].z); acc[t].w = fmaf(x, w4.w, acc[t].w);
+            }
+        }
+    }
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + cg * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(p.shift + cg * 4);
+    float* out = p.out + (size_t)b * p.Ho * p.Wo * p.out_cs + p.out_co;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int oy = ty * T + wave * 4 + (t >> 2), ox = tx * T + (t & 3) * 4 + ps;
+        float4 v;
+        v.x = fmaxf(fmaf(acc[t].x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(acc[t].y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(acc[t].z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(acc[t].w, sc.w, sh.w), 0.f);
+        *reinterpret_cast<float4*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + cg * 4) = v;
+    }
+}
+
+int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st) {
+    ROMP_REQUIRE(op.Cin == 3 && op.Cout == 64 && op.ksize == 3 && op.stride == 2, "stem: expects 3->64 k3 s2");
+    ROMP_REQUIRE(op.H % 32 == 0 && op.W % 32 == 0, "stem: input %dx%d must be a multiple of 32", op.H, op.W);
+    ROMP_REQUIRE((op.out_cstride & 3) == 0 && (op.out_coff & 3) == 0, "stem: output channels must be float4 aligned");
+    StemParams p;
+    p.image = image; p.w = op.weight; p.scale = op.scale; p.shift = op.shift; p.out = out;
+    p.H = op.H; p.W = op.W; p.Ho = op.H / 2; p.Wo = op.W / 2;
+    p.out_cs = op.out_cstride; p.out_co = op.out_coff;
+    p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 16;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+struct FuseParams {
+    const float* t[4]; int shift[4]; int cs[4];
+    float* out; int n_terms, H, W, C4, out_cs, out_co, relu; size_t total;
+};
+
+__global__ __launch_bounds__(256) void fusesum_kernel(FuseParams p) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int c = (int)(r % p.C4) * 4; r /= p.C4;
+        const int x = (int)(r % p.W); r /= p.W;
+        const int y = (int)(r % p.H);
+        const int b = (int)(r / p.H);
+        float4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < p.n_terms) {
+                const int s = p.shift[k];
+                const int h = p.H >> s, w = p.W >> s;
+                const float4 tv = *reinterpret_cast<const float4*>(
+                    p.t[k] + (((size_t)b * h + (y >> s)) * w + (x >> s)) * p.cs[k] + c);
+                if (k == 0) v = tv;
+                else { v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w; }
+            }
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p.out + (((size_t)b * p.H + y) * p.W + x) * p.out_cs + p.out_co + c) = v;
+    }
+}
+
+int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
+                   int out_cstride, int out_coff, int relu, hipStream_t st) {
+    ROMP_REQUIRE(n_terms >= 1 && n_terms <= 4, "fusesum: %d terms unsupported", n_terms);
+    ROMP_REQUIRE((C & 3) == 0 && (out_cstride & 3) == 0 && (out_coff & 3) == 0, "fusesum: channels must be float4 aligned");
+    FuseParams p;
+    for (int k = 0; k < 4; ++k) { p.t[k] = nullptr; p.shift[k] = 0; p.cs[k] = 0; }
+    for (int k = 0; k < n_terms; ++k) {
+        ROMP_REQUIRE((terms[k].cstride & 3) == 0, "fusesum: term stride must be float4 aligned");
+        ROMP_REQUIRE((H >> terms[k].shift) << terms[k].shift == H, "fusesum: term %d shift %d does not divide H", k, terms[k].shift);
+        p.t[k] = terms[k].ptr; p.shift[k] = terms[k].shift; p.cs[k] = terms[k].cstride;
+    }
+    p.out = out; p.n_terms = n_terms; p.H = H; p.W = W; p.C4 = C / 4;
+    p.out_cs = out_cstride; p.out_co = out_coff; p.relu = relu;
+    p.total = (size_t)B * H * W * p.C4;
+    size_t blocks = (p.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(fusesum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+}  // namespace romp

@@ -1,0 +1,97 @@
+"""Image-batch data parallelism: one process per GPU, contiguous static shards, one RCCL
+all-gather of compact per-person records over xGMI.
+
+Replaces the reference's single-process ``nn.DataParallel`` wrapper (simple_romp/romp/main.py:77),
+which scatters the batch, replicates the module per call and gathers the DENSE maps
+((B,1,64,64)+(B,145,64,64) = 2.39 MB/image) to GPU 0 before parsing.  Here each rank runs
+net -> parse -> SMPL on its own shard and only per-person records cross the fabric:
+record = [global image id, flat index, confidence, cam 3, thetas 72, betas 10] = 88 floats
+(352 B/person), optionally + joints (71x3) and vertices (6890x3).
+
+RCCL has no all-gather-v: ranks first all-gather their counts, pad their block to the
+maximum count, all-gather the padded blocks and strip the padding.  Images are independent
+(BN uses running statistics), so there is no other data-path collective.
+"""
+import torch
+import torch.distributed as dist
+
+RECORD_BASE = 88          # img id, flat ind, conf, cam(3), thetas(72), betas(10)
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous shard [lo, hi) of rank; the first (n % world) ranks get one extra item."""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_records(outputs, batch_ids, img_offset, flat_inds=None, with_joints=False, with_verts=False):
+    """Per-person records of the local shard as one float32 matrix (N, R)."""
+    if outputs is None:
+        return None
+    N = outputs['cam'].shape[0]
+    dev = outputs['cam'].device
+    flat = flat_inds if flat_inds is not None else (outputs['center_preds'][:, 1] // 8 * 64 + outputs['center_preds'][:, 0] // 8)
+    cols = [(batch_ids + img_offset).float().view(N, 1), flat.float().view(N, 1), outputs['center_confs'].view(N, 1),
+            outputs['cam'], outputs['smpl_thetas'], outputs['smpl_betas']]
+    if with_joints:
+        cols.append(outputs['joints'].reshape(N, -1))
+    if with_verts:
+        cols.append(outputs['verts'].reshape(N, -1))
+    return torch.cat([c.to(dev).float() for c in cols], 1).contiguous()
+
+
+def record_width(with_joints=False, with_verts=False):
+    return RECORD_BASE + (213 if with_joints else 0) + (6890 * 3 if with_verts else 0)
+
+
+def all_gather_records(local, width, device, group=None):
+    """All-gather-v of (N_r, width) float32 blocks -> (sum N_r, width), rank-major (= image order
+    because shards are contiguous).  `local` may be None (no detections on this rank)."""
+    world = dist.get_world_size(group)
+    n_local = 0 if local is None else local.shape[0]
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=device), group=group)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    if n_max == 0:
+        return torch.zeros(0, width, device=device), counts
+    block = torch.zeros(n_max, width, device=device, dtype=torch.float32)
+    if n_local:
+        block[:n_local] = local
+    gathered = torch.empty(world * n_max, width, device=device, dtype=torch.float32)
+    if device.type == 'cuda' and hasattr(dist, 'all_gather_into_tensor'):
+        dist.all_gather_into_tensor(gathered, block, group=group)      # one RCCL all-gather
+    else:
+        _all_gather_list(gathered, block, world, group)                # gloo (CPU tests)
+    parts = [gathered[r * n_max: r * n_max + counts[r]] for r in range(world)]
+    return torch.cat(parts, 0), counts
+
+
+def _all_gather_list(gathered, block, world, group):
+    outs = list(gathered.chunk(world, 0))
+    dist.all_gather(outs, block, group=group)
+
+
+def unpack_records(rec, with_joints=False, with_verts=False):
+    out = {
+        'image_ids': rec[:, 0].long(), 'flat_inds': rec[:, 1].long(), 'center_confs': rec[:, 2:3],
+        'cam': rec[:, 3:6], 'smpl_thetas': rec[:, 6:78], 'smpl_betas': rec[:, 78:88],
+    }
+    o = RECORD_BASE
+    if with_joints:
+        out['joints'] = rec[:, o:o + 213].reshape(-1, 71, 3)
+        o += 213
+    if with_verts:
+        out['verts'] = rec[:, o:o + 6890 * 3].reshape(-1, 6890, 3)
+    return out
+
+
+def sharded_forward(model, images_local, img_offset, with_joints=True, with_verts=False, group=None):
+    """Run `model.forward_batch` (romp_amd.ROMP) on this rank's shard and all-gather the records.
+    Returns (dict of gathered tensors, per-rank counts)."""
+    outputs, batch_ids = model.forward_batch(images_local)
+    dev = images_local.device
+    rec = pack_records(outputs, batch_ids, img_offset, with_joints=with_joints, with_verts=with_verts)
+    allrec, counts = all_gather_records(rec, record_width(with_joints, with_verts), dev, group)
+    return unpack_records(allrec, with_joints, with_verts), counts

@@ -1,0 +1,104 @@
+"""ctypes binding of libromp_hip.so (the C ABI declared in include/romp_hip.h).
+
+PyTorch-ROCm is plumbing here: it owns device memory and streams; every arithmetic step of
+the hot path is a call into the HIP library.  The library is REQUIRED -- there is no CPU
+or eager-PyTorch fallback in the product path; a missing/unbuildable extension raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libromp_hip.so')
+
+BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
+OP_STEM, OP_CONV, OP_FUSESUM = 1, 2, 3
+
+
+class RompOp(C.Structure):
+    """Mirror of `struct romp_op` (include/romp_hip.h)."""
+    _fields_ = [
+        ('kind', C.c_int32),
+        ('in_buf', C.c_int32), ('out_buf', C.c_int32), ('res_buf', C.c_int32),
+        ('H', C.c_int32), ('W', C.c_int32),
+        ('Cin', C.c_int32), ('Cout', C.c_int32),
+        ('ksize', C.c_int32), ('stride', C.c_int32), ('relu', C.c_int32),
+        ('groups', C.c_int32),
+        ('in_cstride', C.c_int32), ('in_coff', C.c_int32), ('in_gstride', C.c_int32),
+        ('out_cstride', C.c_int32), ('out_coff', C.c_int32), ('out_gstride', C.c_int32),
+        ('res_cstride', C.c_int32), ('res_coff', C.c_int32), ('res_gstride', C.c_int32),
+        ('cin_pad', C.c_int32), ('cout_pad', C.c_int32),
+        ('n_terms', C.c_int32),
+        ('term_buf', C.c_int32 * 4), ('term_shift', C.c_int32 * 4), ('term_cstride', C.c_int32 * 4),
+        ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+class RompHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libromp_hip.so (building it in-tree with hipcc if it is missing).  torch must be
+    imported first so that the library binds to the same libamdhip64 as PyTorch-ROCm."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's libamdhip64.so.7 before ours resolves it)
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p, f = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_float
+    sigs = {
+        'romp_abi_version': (C.c_int, []),
+        'romp_last_error': (C.c_char_p, []),
+        'romp_net_create': (C.c_int, [C.POINTER(vp), C.POINTER(RompOp), i32, i64p, i32, i32]),
+        'romp_net_forward': (C.c_int, [vp, vp, i32, vp, vp, vp]),
+        'romp_net_read_buffer': (C.c_int, [vp, i32, i32, vp, C.c_int64, vp]),
+        'romp_net_write_buffer': (C.c_int, [vp, i32, vp, C.c_int64, vp]),
+        'romp_net_set_mode': (C.c_int, [vp, i32]),
+        'romp_net_set_graph': (C.c_int, [vp, i32]),
+        'romp_net_profile': (C.c_int, [vp, vp, i32, vp, vp, vp, C.POINTER(C.c_float), i32]),
+        'romp_net_destroy': (None, [vp]),
+        'romp_conv_forward': (C.c_int, [C.POINTER(RompOp), vp, vp, vp, i32, i32, vp]),
+        'romp_conv_describe': (C.c_int, [C.POINTER(RompOp), i32, C.c_char_p, i32]),
+        'romp_parse': (C.c_int, [vp, vp, i32, f, i32, C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'romp_rot6d_to_aa': (C.c_int, [vp, i32, vp, vp]),
+        'smpl_ctx_create': (C.c_int, [C.POINTER(vp), vp, vp, i32, vp, vp, vp, i64p, vp, vp, i64p, i32, vp]),
+        'smpl_forward': (C.c_int, [vp, vp, i32, vp, i32, i32, vp, vp, vp]),
+        'smpl_ctx_destroy': (None, [vp]),
+        'romp_project': (C.c_int, [vp, i32, i32, vp, C.POINTER(C.c_float), vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)      # raises AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.romp_abi_version() != 1:
+        raise RompHipError('libromp_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_forward', 'romp_net_read_buffer',
+           'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_profile', 'romp_net_destroy',
+           'romp_conv_forward', 'romp_conv_describe', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
+           'romp_project']
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().romp_last_error()
+        raise RompHipError('libromp_hip error %d: %s' % (rc, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor as c_void_p (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,156 @@
+"""Drop-in for ``simple_romp/romp/main.py``: ``romp_settings`` (:17-60), ``ROMP`` (:64-176), ``main`` (:178-204).
+
+    import romp_amd as romp
+    model = romp.ROMP(romp.main.default_settings)
+    outputs = model(cv2.imread(path))          # dict of numpy arrays, or None
+
+Same settings Namespace, same dict keys/dtypes/shapes, ``None`` when nobody is detected.
+Every arithmetic stage (network, parsing, SMPL, projection) runs in libromp_hip.so on the
+MI355X; there is NO CPU path here -- ``--GPU -1`` (or a missing HIP device/extension) raises.
+``forward_batch`` is an extension of the API for batched throughput (the reference has none).
+"""
+import argparse
+import os
+import os.path as osp
+import sys
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import lib as L
+from .net import RompNet
+from .post_parser import (CenterMap, SMPL_parser, body_mesh_projection2image, convert_cam_to_3d_trans,
+                          parsing_outputs)
+from .utils import ResultSaver, convert_tensor2numpy, determine_device, img_preprocess
+
+
+def romp_settings(input_args=sys.argv[1:]):
+    """main.py:17-60 -- identical flags and defaults (auto-download is dropped: no network)."""
+    parser = argparse.ArgumentParser(description='ROMP: Monocular, One-stage, Regression of Multiple 3D People')
+    parser.add_argument('-m', '--mode', type=str, default='image', help='Inferece mode, including image, video, webcam')
+    parser.add_argument('-i', '--input', type=str, default=None, help='Path to the input image / video')
+    parser.add_argument('-o', '--save_path', type=str, default=osp.join(osp.expanduser("~"), 'ROMP_results'), help='Path to save the results')
+    parser.add_argument('--GPU', type=int, default=0, help='The gpu device number to run the inference on.')
+    parser.add_argument('--onnx', action='store_true', help='(reference flag; the HIP path replaces the ONNX session)')
+    parser.add_argument('-t', '--temporal_optimize', action='store_true', help='Whether to use OneEuro filter to smooth the results')
+    parser.add_argument('--center_thresh', type=float, default=0.25, help='The confidence threshold of positive detection in 2D human body center heatmap.')
+    parser.add_argument('--show_largest', action='store_true', help='Whether to show the largest person only')
+    parser.add_argument('-sc', '--smooth_coeff', type=float, default=3., help='The smoothness coeff of OneEuro filter, the smaller, the smoother.')
+    parser.add_argument('--calc_smpl', action='store_false', help='Whether to calculate the smpl mesh from estimated SMPL parameters')
+    parser.add_argument('--render_mesh', action='store_true', help='Whether to render the estimated 3D mesh mesh to image')
+    parser.add_argument('--renderer', type=str, default='sim3dr', help='Choose the renderer for visualizaiton')
+    parser.add_argument('--show', action='store_true', help='Whether to show the rendered results')
+    parser.add_argument('--show_items', type=str, default='mesh', help='The items to visualized')
+    parser.add_argument('--save_video', action='store_true', help='Whether to save the video results')
+    parser.add_argument('--frame_rate', type=int, default=24, help='The frame_rate of saved video results')
+    parser.add_argument('--smpl_path', type=str, default=osp.join(osp.expanduser("~"), '.romp', 'SMPL_NEUTRAL.pth'), help='The path of smpl model file')
+    parser.add_argument('--model_path', type=str, default=osp.join(osp.expanduser("~"), '.romp', 'ROMP.pkl'), help='The path of ROMP checkpoint')
+    parser.add_argument('--model_onnx_path', type=str, default=osp.join(osp.expanduser("~"), '.romp', 'ROMP.onnx'), help='The path of ROMP onnx checkpoint')
+    parser.add_argument('--root_align', type=bool, default=False, help='Please set this config as True to use the ROMP checkpoints trained by yourself.')
+    parser.add_argument('--webcam_id', type=int, default=0, help='The Webcam ID.')
+    parser.add_argument('--max_batch', type=int, default=32, help='[romp_amd] largest batch forward_batch will be called with')
+    args = parser.parse_args(input_args)
+    if not torch.cuda.is_available():
+        args.GPU = -1
+        args.temporal_optimize = False
+    if args.show:
+        args.render_mesh = True
+    if args.render_mesh or args.show_largest:
+        args.calc_smpl = True
+    if not os.path.exists(args.smpl_path):
+        alt = args.smpl_path.replace('SMPL_NEUTRAL.pth', 'smpl_packed_info.pth')
+        if os.path.exists(alt):
+            args.smpl_path = alt
+    return args
+
+
+default_settings = romp_settings(input_args=[])
+
+
+class ROMP(nn.Module):
+    def __init__(self, romp_settings, state_dict=None, smpl_model=None):
+        """`state_dict` / `smpl_model` optionally supply already-loaded weights (dicts with the
+        reference's schemas) instead of settings.model_path / settings.smpl_path."""
+        super(ROMP, self).__init__()
+        self.settings = romp_settings
+        if self.settings.GPU == -1:
+            raise L.RompHipError('romp_amd is the MI355X path of ROMP: it needs a HIP device (GPU=%d); '
+                                 'there is no CPU fallback' % self.settings.GPU)
+        if self.settings.render_mesh or self.settings.temporal_optimize:
+            raise NotImplementedError('rendering / temporal smoothing are outside the MI355X hot path (SURVEY.md §8f)')
+        self.tdevice = determine_device(self.settings.GPU)
+        self._build_model_(state_dict)
+        self._initilization_(smpl_model)
+
+    def _build_model_(self, state_dict=None):
+        """main.py:72-77: load the state_dict and bind it into the HIP network context."""
+        if state_dict is None:
+            state_dict = torch.load(self.settings.model_path, map_location='cpu')
+        self.model = RompNet(state_dict, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32))
+
+    def _initilization_(self, smpl_model=None):
+        self.centermap_parser = CenterMap(conf_thresh=self.settings.center_thresh)
+        if self.settings.calc_smpl:
+            self.smpl_parser = SMPL_parser(smpl_model if smpl_model is not None else self.settings.smpl_path).to(self.tdevice)
+
+    def single_image_forward(self, image):
+        """main.py:106-115."""
+        input_image, image_pad_info = img_preprocess(image)
+        center_maps, params_maps = self.model(input_image.to(self.tdevice))
+        parsed_results = parsing_outputs(center_maps, params_maps, self.centermap_parser)
+        return parsed_results, image_pad_info
+
+    def _finish(self, outputs, image_pad_info):
+        outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])                      # main.py:166
+        if self.settings.calc_smpl:
+            outputs = self.smpl_parser(outputs, root_align=self.settings.root_align)        # main.py:168
+            outputs.update(body_mesh_projection2image(outputs['joints'], outputs['cam'], vertices=outputs['verts'],
+                                                      input2org_offsets=image_pad_info))   # main.py:169
+        return outputs
+
+    def forward(self, image, signal_ID=0, **kwargs):
+        """main.py:160-176: BGR uint8 HxWx3 numpy -> dict of numpy arrays, or None."""
+        outputs, image_pad_info = self.single_image_forward(image)
+        if outputs is None:
+            return None
+        return convert_tensor2numpy(self._finish(outputs, image_pad_info))
+
+    @torch.no_grad()
+    def forward_batch(self, images, return_tensors=True):
+        """[extension] images: float32 (B,512,512,3) 0..255 already pre-processed, on the device.
+        Runs net -> parse -> SMPL for the whole batch; returns (outputs dict, batch_ids) with device
+        tensors (verts (N,6890,3), joints (N,71,3), cam, smpl_thetas, smpl_betas, ...), or
+        (None, None) if nobody is detected."""
+        center, params = self.model.forward_nhwc(images)
+        outputs, batch_ids = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True)
+        if outputs is None:
+            return None, None
+        outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])
+        if self.settings.calc_smpl:
+            outputs = self.smpl_parser(outputs, root_align=self.settings.root_align)
+        if not return_tensors:
+            outputs = convert_tensor2numpy(outputs)
+        return outputs, batch_ids
+
+
+def main():
+    """main.py:178-204 (image mode; video/webcam need OpenCV)."""
+    args = romp_settings()
+    romp = ROMP(args)
+    if args.mode == 'image':
+        saver = ResultSaver(args.mode, args.save_path)
+        try:
+            import cv2
+            image = cv2.imread(args.input)
+        except ImportError:
+            from PIL import Image
+            image = np.asarray(Image.open(args.input).convert('RGB'))[:, :, ::-1]
+        outputs = romp(image)
+        saver(outputs, args.input)
+    else:
+        raise NotImplementedError('mode %s needs OpenCV capture; only --mode image is wired here' % args.mode)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,89 @@
+"""RompNet -- device-side ROMPv1 (HRNet-32 + head) behind the reference's network seam.
+
+Replaces ``ROMPv1.forward`` (simple_romp/romp/model.py:470-481) / the ONNX session call at
+``main.py:109-112``: ``(B,512,512,3) float 0..255 -> center_maps (B,1,64,64),
+params_maps (B,145,64,64)``.  PyTorch-ROCm owns the I/O tensors; all arithmetic is in
+libromp_hip.so (csrc/conv_mfma.hip, stem_fuse.hip, net.hip).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .plan import Program, build_romp_hrnet32, coord_channels
+
+
+class RompNet:
+    def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
+        self.lib = L.load()
+        self.max_batch = int(max_batch)
+        self.input_size = input_size
+        with torch.cuda.device(self.device):
+            self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size)
+            ops = self.program.op_array()
+            sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
+            h = C.c_void_p()
+            L.check(self.lib.romp_net_create(C.byref(h), ops, len(self.program.ops), sizes,
+                                             len(self.program.buf_floats), self.max_batch))
+            self._h = h
+            fs = input_size // 4
+            coords = coord_channels(self.max_batch, fs, self.device)
+            L.check(self.lib.romp_net_write_buffer(self._h, self.program.head_in_buf, L.ptr(coords),
+                                                   coords.numel(), L.stream_ptr(self.device)))
+            torch.cuda.synchronize(self.device)
+        if use_graph:
+            self.set_graph(True)
+
+    # -- configuration -------------------------------------------------------------------
+    def set_mode(self, mode):
+        """0 = MFMA kernels (default), 1 = naive direct-conv cross-check kernels."""
+        L.check(self.lib.romp_net_set_mode(self._h, int(mode)))
+
+    def set_graph(self, enable):
+        L.check(self.lib.romp_net_set_graph(self._h, int(bool(enable))))
+
+    # -- forward -------------------------------------------------------------------------
+    def forward_nhwc(self, image, center_out=None, params_out=None):
+        """image (B,H,W,3) float32 on device -> center (B,64,64), params (B,64,64,145) NHWC."""
+        assert image.dtype == torch.float32 and image.is_cuda and image.dim() == 4 and image.shape[-1] == 3
+        image = image.contiguous()
+        B = image.shape[0]
+        ms = self.input_size // 8
+        if center_out is None:
+            center_out = torch.empty(B, ms, ms, device=self.device, dtype=torch.float32)
+        if params_out is None:
+            params_out = torch.empty(B, ms, ms, 145, device=self.device, dtype=torch.float32)
+        L.check(self.lib.romp_net_forward(self._h, L.ptr(image), B, L.ptr(center_out), L.ptr(params_out),
+                                          L.stream_ptr(self.device)))
+        return center_out, params_out
+
+    def __call__(self, image):
+        """Reference layout: center_maps (B,1,64,64), params_maps (B,145,64,64) (views, no copy)."""
+        c, p = self.forward_nhwc(image)
+        return c.unsqueeze(1), p.permute(0, 3, 1, 2)
+
+    def read_buffer(self, buf, B):
+        n = self.program.buf_floats[buf] * B
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        L.check(self.lib.romp_net_read_buffer(self._h, buf, B, L.ptr(out), n, L.stream_ptr(self.device)))
+        return out
+
+    def profile(self, image, iters=3):
+        """Per-op mean milliseconds (HIP events on the current stream)."""
+        B = image.shape[0]
+        ms = self.input_size // 8
+        c = torch.empty(B, ms, ms, device=self.device)
+        p = torch.empty(B, ms, ms, 145, device=self.device)
+        out = (C.c_float * len(self.program.ops))()
+        L.check(self.lib.romp_net_profile(self._h, L.ptr(image.contiguous()), B, L.ptr(c), L.ptr(p),
+                                          L.stream_ptr(self.device), out, iters))
+        return list(out)
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and getattr(self, 'lib', None) is not None:
+            self.lib.romp_net_destroy(h)
+            self._h = None

@@ -1,0 +1,335 @@
+"""Lower a ROMP state_dict (HRNet-32 + ROMP head) to the layer program of libromp_hip.so.
+
+Host-side mirror of the reference's model definition (simple_romp/romp/model.py):
+``HigherResolutionNet`` :246-417 (stem :338-344, layer1 :345, transitions :254-287, stages
+:305-334 / ``HighResolutionModule`` :129-244) and ``ROMPv1`` head :427-481.  The state_dict
+key layout (1 851 entries) is the weight interface; this module folds
+every inference BatchNorm into a per-channel (scale, shift), re-packs conv weights for the
+MFMA implicit-GEMM kernels and assigns NHWC activation buffers with liveness-based reuse.
+
+What is NOT here: any arithmetic of the hot path.  The program is executed by
+``csrc/net.hip``; this file only decides *what* is launched on *which* buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from .lib import BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_CONV, OP_FUSESUM, OP_STEM, RompOp
+
+BN_EPS = 1e-5
+HEAD_IN_CH = 40          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 8
+
+
+@dataclass
+class Act:
+    """An NHWC activation living in arena buffer `buf` (channel stride may exceed C)."""
+    buf: int
+    C: int
+    H: int
+    W: int
+    cstride: int
+    coff: int = 0
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def fold_bn(sd, bn, cout, bias=None):
+    """scale = gamma/sqrt(var+eps), shift = beta - mean*scale (+ scale*bias); float64 -> float32."""
+    if bn is None:
+        scale = torch.ones(cout, dtype=torch.float64)
+        shift = torch.zeros(cout, dtype=torch.float64)
+    else:
+        g, b = sd[bn + '.weight'].double(), sd[bn + '.bias'].double()
+        m, v = sd[bn + '.running_mean'].double(), sd[bn + '.running_var'].double()
+        scale = g / torch.sqrt(v + BN_EPS)
+        shift = b - m * scale
+    if bias is not None:
+        shift = shift + scale * bias.double()
+    return scale.float(), shift.float()
+
+
+def conv_pads(cin, cout, ksize):
+    """Padded (cin, cout) of the packed weight: cin to the kernel's channel-chunk size,
+    cout to the 32-wide MFMA N-block (64 when the layer has >= 64 channels)."""
+    if ksize == 1:
+        ck = 32 if cin % 32 == 0 else 16
+    else:
+        ck = 16 if cin % 16 == 0 else 8
+    return _round_up(cin, ck), _round_up(cout, 64 if cout >= 64 else 32)
+
+
+def pack_conv_weight(w, cin_pad, cout_pad):
+    """OIHW (cout,cin,k,k) -> [tap][cin_pad/4][cout_pad][4] (zero padded)."""
+    cout, cin, k, _ = w.shape
+    t = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+    full = torch.zeros(k * k, cin_pad, cout_pad, dtype=torch.float32)
+    full[:, :cin, :cout] = t
+    return full.reshape(k * k, cin_pad // 4, 4, cout_pad).permute(0, 1, 3, 2).contiguous()
+
+
+class Program:
+    """The lowered network: ops (ctypes), packed constants (kept alive here), buffer sizes."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops: List[RompOp] = []
+        self.names: List[str] = []
+        self.flops: List[float] = []          # per image
+        self.bytes: List[float] = []          # algorithmic HBM bytes per image (in + out + res)
+        self.consts: List[torch.Tensor] = []
+        self.buf_floats: List[int] = []
+        self._free: Dict[int, List[int]] = {}
+        self.persistent = set()
+        self.head_in_buf: Optional[int] = None
+
+    # ---- buffers -------------------------------------------------------------------------
+    def alloc(self, floats, persistent=False):
+        lst = self._free.get(floats)
+        if lst and not persistent:
+            return lst.pop()
+        self.buf_floats.append(int(floats))
+        b = len(self.buf_floats) - 1
+        if persistent:
+            self.persistent.add(b)
+        return b
+
+    def free(self, act: Act):
+        if act.buf >= 0 and act.buf not in self.persistent:
+            lst = self._free.setdefault(self.buf_floats[act.buf], [])
+            assert act.buf not in lst, 'double free of buffer %d' % act.buf
+            lst.append(act.buf)
+
+    def new_act(self, C_, H, W):
+        return Act(self.alloc(C_ * H * W), C_, H, W, C_)
+
+    def _dev(self, t):
+        t = t.to(self.device).contiguous()
+        self.consts.append(t)
+        return t
+
+    # ---- ops -----------------------------------------------------------------------------
+    def conv(self, name, x: Act, w, scale, shift, ksize, stride, relu, res: Optional[Act] = None,
+             out: Optional[Act] = None, groups=1, out_buf_special=None, out_cstride=None, out_coff=0):
+        """w: list (per group) of OIHW tensors; scale/shift: list of per-group vectors."""
+        cout, cin = w[0].shape[0], w[0].shape[1]
+        cin_phys = x.C // groups if groups > 1 else x.C      # channels the loader may touch
+        cin_pad, cout_pad = conv_pads(cin_phys, cout, ksize)
+        assert cin <= cin_phys
+        pw = torch.stack([pack_conv_weight(wi, cin_pad, cout_pad) for wi in w])
+        ps = torch.zeros(groups, cout_pad)
+        pb = torch.zeros(groups, cout_pad)
+        for g in range(groups):
+            ps[g, :cout], pb[g, :cout] = scale[g], shift[g]
+        pw, ps, pb = self._dev(pw), self._dev(ps), self._dev(pb)
+        Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
+        Wo = (x.W + 2 * (ksize // 2) - ksize) // stride + 1
+        if out is None and out_buf_special is None:
+            out = self.new_act(cout * groups, Ho, Wo)
+        op = RompOp()
+        op.kind, op.in_buf, op.res_buf = OP_CONV, x.buf, (res.buf if res is not None else BUF_NONE)
+        op.out_buf = out_buf_special if out_buf_special is not None else out.buf
+        op.H, op.W, op.Cin, op.Cout = x.H, x.W, cin_phys, cout
+        op.ksize, op.stride, op.relu, op.groups = ksize, stride, int(relu), groups
+        op.in_cstride, op.in_coff, op.in_gstride = x.cstride, x.coff, (cin_phys if groups > 1 else 0)
+        if out_buf_special is not None:
+            op.out_cstride, op.out_coff, op.out_gstride = out_cstride, out_coff, 0
+        else:
+            op.out_cstride, op.out_coff, op.out_gstride = out.cstride, out.coff, (cout if groups > 1 else 0)
+        if res is not None:
+            op.res_cstride, op.res_coff, op.res_gstride = res.cstride, res.coff, (cout if groups > 1 else 0)
+        op.cin_pad, op.cout_pad = cin_pad, cout_pad
+        op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+        self.ops.append(op)
+        self.names.append(name)
+        self.flops.append(2.0 * Ho * Wo * cout * cin * ksize * ksize * groups)
+        nbytes = 4.0 * (x.H * x.W * cin_phys * groups + Ho * Wo * cout * groups * (2 if res is not None else 1))
+        self.bytes.append(nbytes)
+        return out
+
+    def stem(self, name, w, scale, shift, H, W):
+        out = self.new_act(64, H // 2, W // 2)
+        pw = self._dev(w.permute(2, 3, 1, 0).reshape(27, 64).contiguous())
+        ps, pb = self._dev(scale), self._dev(shift)
+        op = RompOp()
+        op.kind, op.in_buf, op.out_buf, op.res_buf = OP_STEM, BUF_IMAGE, out.buf, BUF_NONE
+        op.H, op.W, op.Cin, op.Cout, op.ksize, op.stride, op.relu, op.groups = H, W, 3, 64, 3, 2, 1, 1
+        op.in_cstride, op.out_cstride = 3, 64
+        op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+        self.ops.append(op)
+        self.names.append(name)
+        self.flops.append(2.0 * (H // 2) * (W // 2) * 64 * 27)
+        self.bytes.append(4.0 * (H * W * 3 + (H // 2) * (W // 2) * 64))
+        return out
+
+    def fusesum(self, name, terms: List[Act], shifts: List[int], relu=True, out: Optional[Act] = None):
+        t0 = terms[0]
+        H, W = t0.H << shifts[0], t0.W << shifts[0]
+        if out is None:
+            out = self.new_act(t0.C, H, W)
+        op = RompOp()
+        op.kind, op.in_buf, op.out_buf, op.res_buf = OP_FUSESUM, BUF_NONE, out.buf, BUF_NONE
+        op.H, op.W, op.Cin, op.Cout, op.relu = H, W, t0.C, t0.C, int(relu)
+        op.out_cstride, op.out_coff = out.cstride, out.coff
+        op.n_terms = len(terms)
+        nbytes = 4.0 * H * W * t0.C
+        for k, (t, s) in enumerate(zip(terms, shifts)):
+            assert t.C == t0.C and t.coff == 0 and (t.H << s) == H
+            op.term_buf[k], op.term_shift[k], op.term_cstride[k] = t.buf, s, t.cstride
+            nbytes += 4.0 * t.H * t.W * t.C
+        self.ops.append(op)
+        self.names.append(name)
+        self.flops.append(float(H * W * t0.C * (len(terms) - 1)))
+        self.bytes.append(nbytes)
+        return out
+
+    def op_array(self):
+        arr = (RompOp * len(self.ops))()
+        for i, o in enumerate(self.ops):
+            arr[i] = o
+        return arr
+
+
+def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> Program:
+    """state_dict of ROMPv1 (model.py:420-481) -> Program."""
+    sd = {k: v.detach().float().cpu() for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+    P = Program(device)
+
+    def cbr(name, x, conv, bn, k, stride, relu, res=None, out=None):
+        w = sd[conv + '.weight']
+        s, b = fold_bn(sd, bn, w.shape[0], sd.get(conv + '.bias'))
+        return P.conv(name, x, [w], [s], [b], k, stride, relu, res=res, out=out)
+
+    bb = 'backbone.'
+    # ---- stem (model.py:384-390)
+    s, b = fold_bn(sd, bb + 'bn1', 64)
+    x = P.stem('stem.conv1', sd[bb + 'conv1.weight'], s, b, input_size, input_size)
+    y = cbr('stem.conv2', x, bb + 'conv2', bb + 'bn2', 3, 2, True)
+    P.free(x)
+    x = y
+    # ---- layer1: 4 Bottlenecks (model.py:103-123, :345)
+    for i in range(4):
+        p = f'{bb}layer1.{i}.'
+        t1 = cbr(p + 'conv1', x, p + 'conv1', p + 'bn1', 1, 1, True)
+        t2 = cbr(p + 'conv2', t1, p + 'conv2', p + 'bn2', 3, 1, True)
+        P.free(t1)
+        if (p + 'downsample.0.weight') in sd:
+            r = cbr(p + 'downsample', x, p + 'downsample.0', p + 'downsample.1', 1, 1, False)
+            P.free(x)
+        else:
+            r = x
+        y = cbr(p + 'conv3', t2, p + 'conv3', p + 'bn3', 1, 1, True, res=r)
+        P.free(t2)
+        P.free(r)
+        x = y
+    # ---- transition1 (model.py:393-398)
+    xs = [cbr('transition1.0', x, bb + 'transition1.0.0', bb + 'transition1.0.1', 3, 1, True),
+          cbr('transition1.1', x, bb + 'transition1.1.0.0', bb + 'transition1.1.0.1', 3, 2, True)]
+    P.free(x)
+
+    def hr_module(prefix, xs, n_out, final_out: Optional[Act] = None):
+        """HighResolutionModule.forward (model.py:226-244)."""
+        nb = len(xs)
+        xs = list(xs)
+        for br in range(nb):                                     # branches: 4 BasicBlocks each
+            for k in range(4):
+                q = f'{prefix}branches.{br}.{k}.'
+                t = cbr(q + 'conv1', xs[br], q + 'conv1', q + 'bn1', 3, 1, True)
+                y = cbr(q + 'conv2', t, q + 'conv2', q + 'bn2', 3, 1, True, res=xs[br])
+                P.free(t)
+                P.free(xs[br])
+                xs[br] = y
+        outs = []
+        for i in range(n_out):
+            terms, shifts, temps = [], [], []
+            for j in range(nb):
+                q = f'{prefix}fuse_layers.{i}.{j}.'
+                if j == i:
+                    terms.append(xs[j]); shifts.append(0)
+                elif j > i:                                      # 1x1 conv + BN, upsample folded into fusesum
+                    t = cbr(q + 'up', xs[j], q + '0', q + '1', 1, 1, False)
+                    terms.append(t); shifts.append(j - i); temps.append(t)
+                else:                                            # chain of stride-2 3x3 convs
+                    t = xs[j]
+                    for k in range(i - j):
+                        t2 = cbr(f'{q}{k}', t, f'{q}{k}.0', f'{q}{k}.1', 3, 2, k != i - j - 1)
+                        if t is not xs[j]:
+                            P.free(t)
+                        t = t2
+                    terms.append(t); shifts.append(0); temps.append(t)
+            outs.append(P.fusesum(f'{prefix}fuse.{i}', terms, shifts, True,
+                                  out=final_out if (final_out is not None and i == 0) else None))
+            for t in temps:
+                P.free(t)
+        for xj in xs:
+            P.free(xj)
+        return outs
+
+    ys = hr_module(bb + 'stage2.0.', xs, 2)
+    # ---- transition2 / stage3 (model.py:401-407)
+    xs = [ys[0], ys[1], cbr('transition2.2', ys[-1], bb + 'transition2.2.0.0', bb + 'transition2.2.0.1', 3, 2, True)]
+    for m in range(4):
+        xs = hr_module(f'{bb}stage3.{m}.', xs, 3)
+    # ---- transition3 / stage4 (model.py:409-416)
+    xs = [xs[0], xs[1], xs[2],
+          cbr('transition3.3', xs[-1], bb + 'transition3.3.0.0', bb + 'transition3.3.0.1', 3, 2, True)]
+    for m in range(2):
+        xs = hr_module(f'{bb}stage4.{m}.', xs, 4)
+    # last module emits branch 0 only -> straight into the head input buffer (32 of 40 channels);
+    # channels 32,33 hold the constant CoordConv maps (model.py:473), 34..39 are zero padding.
+    fs = input_size // 4
+    P.head_in_buf = P.alloc(HEAD_IN_CH * fs * fs, persistent=True)
+    head_in = Act(P.head_in_buf, 32, fs, fs, HEAD_IN_CH)
+    hr_module(f'{bb}stage4.2.', xs, 1, final_out=head_in)
+    head_x = Act(P.head_in_buf, HEAD_IN_CH, fs, fs, HEAD_IN_CH)
+
+    # ---- head (model.py:445-481): the three towers share their input; first conv runs as one
+    # 34->192 conv, the BasicBlocks as 3-group convs, then three 1x1 output convs.
+    heads = (1, 2, 3)                                            # params(142), center(1), cam(3)
+    w0, s0, b0 = [], [], []
+    for h in heads:
+        p = f'final_layers.{h}.0.'
+        w = sd[p + '0.weight']
+        wp = torch.zeros(64, HEAD_IN_CH, 3, 3)
+        wp[:, :34] = w
+        s, b = fold_bn(sd, p + '1', 64, sd[p + '0.bias'])
+        w0.append(wp); s0.append(s); b0.append(b)
+    t = P.conv('head.conv0', head_x, [torch.cat(w0, 0)], [torch.cat(s0)], [torch.cat(b0)], 3, 2, True)
+    for blk in range(2):
+        ws1, ss1, bs1, ws2, ss2, bs2 = [], [], [], [], [], []
+        for h in heads:
+            q = f'final_layers.{h}.1.{blk}.0.'
+            ws1.append(sd[q + 'conv1.weight']); s, b = fold_bn(sd, q + 'bn1', 64); ss1.append(s); bs1.append(b)
+            ws2.append(sd[q + 'conv2.weight']); s, b = fold_bn(sd, q + 'bn2', 64); ss2.append(s); bs2.append(b)
+        u = P.conv(f'head.block{blk}.conv1', t, ws1, ss1, bs1, 3, 1, True, groups=3)
+        v = P.conv(f'head.block{blk}.conv2', u, ws2, ss2, bs2, 3, 1, True, res=t, groups=3)
+        P.free(u)
+        P.free(t)
+        t = v
+    for gi, h in enumerate(heads):
+        p = f'final_layers.{h}.2'
+        w = sd[p + '.weight']
+        s, b = fold_bn(sd, None, w.shape[0], sd[p + '.bias'])
+        xin = Act(t.buf, 64, t.H, t.W, t.cstride, 64 * gi)
+        if h == 2:
+            P.conv('head.center', xin, [w], [s], [b], 1, 1, False, out_buf_special=BUF_CENTER, out_cstride=1, out_coff=0)
+        else:   # params_maps = cat([cam_maps, params_maps], 1)  (model.py:480)
+            P.conv('head.params' if h == 1 else 'head.cam', xin, [w], [s], [b], 1, 1, False,
+                   out_buf_special=BUF_PARAMS, out_cstride=145, out_coff=3 if h == 1 else 0)
+    P.free(t)
+    return P
+
+
+def coord_channels(max_batch, size, device):
+    """Initial content of the head input buffer: CoordConv maps in channels 32,33
+    (get_coord_maps model.py:8-37: ch0 varies along W, ch1 along H), zeros elsewhere."""
+    r = torch.arange(size, dtype=torch.float32) / (size - 1) * 2 - 1
+    buf = torch.zeros(max_batch, size, size, HEAD_IN_CH)
+    buf[..., 32] = r.view(1, 1, size)
+    buf[..., 33] = r.view(1, size, 1)
+    return buf.to(device)

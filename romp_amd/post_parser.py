@@ -1,0 +1,187 @@
+"""Host-side mirror of simple_romp/romp/post_parser.py for the HIP path.
+
+Same names and argument meaning as the reference (``CenterMap``, ``parsing_outputs``,
+``SMPL_parser``, ``body_mesh_projection2image``), but every arithmetic step is one call
+into libromp_hip.so (csrc/parse.hip, csrc/smpl.hip).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import lib as L
+from .smpl import SMPL
+
+
+class CenterMap(object):
+    """post_parser.py:8-25 -- holds the parse configuration (size 64, K = 64 persons)."""
+
+    def __init__(self, conf_thresh):
+        self.size = 64
+        self.max_person = 64
+        self.sigma = 1
+        self.conf_thresh = conf_thresh
+
+    def parse_centermap(self, center_maps, params_maps_nhwc=None):
+        """post_parser.py:27-47.  Returns batch_ids, flat_inds, center_yxs, scores (device tensors).
+        Order: batch-major, score-descending inside an image (ties: lower flat index)."""
+        r = _parse(center_maps, params_maps_nhwc, self.conf_thresh, self.max_person)
+        if r is None:
+            e = torch.empty(0, device=center_maps.device)
+            return e.long(), e.long(), e.reshape(0, 2), e
+        yx = torch.stack([(r['flat_inds'] // self.size).float(), (r['flat_inds'] % self.size).float()], 1)
+        return r['batch_ids'], r['flat_inds'], yx, r['scores']
+
+
+def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person):
+    lib = L.load()
+    dev = center_maps.device
+    if dev.type != 'cuda':
+        raise L.RompHipError('parsing runs on the HIP device only (no CPU fallback)')
+    cm = center_maps.reshape(center_maps.shape[0], 64, 64).contiguous().float()
+    B = cm.shape[0]
+    if params_maps_nhwc is None:
+        params_maps_nhwc = torch.zeros(B, 64, 64, 145, device=dev)
+    pm = params_maps_nhwc.contiguous()
+    assert pm.shape == (B, 64, 64, 145) and pm.dtype == torch.float32
+    cap = B * max_person
+    i32 = dict(device=dev, dtype=torch.int32)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {
+        'batch_ids': torch.empty(cap, **i32), 'flat_inds': torch.empty(cap, **i32),
+        'scores': torch.empty(cap, **f32), 'params_pred': torch.empty(cap, 145, **f32),
+        'cam': torch.empty(cap, 3, **f32), 'smpl_thetas': torch.empty(cap, 72, **f32),
+        'smpl_betas': torch.empty(cap, 10, **f32), 'center_preds': torch.empty(cap, 2, **i32),
+    }
+    ws = torch.empty(B * (2 * max_person + 2), **i32)
+    n = C.c_int32(0)
+    with torch.cuda.device(dev):
+        L.check(lib.romp_parse(L.ptr(cm), L.ptr(pm), B, float(conf_thresh), int(max_person), C.byref(n),
+                               L.ptr(out['batch_ids']), L.ptr(out['flat_inds']), L.ptr(out['scores']),
+                               L.ptr(out['params_pred']), L.ptr(out['cam']), L.ptr(out['smpl_thetas']),
+                               L.ptr(out['smpl_betas']), L.ptr(out['center_preds']), L.ptr(ws), L.stream_ptr(dev)))
+    N = n.value
+    if N == 0:
+        return None
+    out = {k: v[:N] for k, v in out.items()}
+    out['batch_ids'] = out['batch_ids'].long()
+    out['flat_inds'] = out['flat_inds'].long()
+    out['center_preds'] = out['center_preds'].long()
+    return out
+
+
+def parsing_outputs(center_maps, params_maps, centermap_parser, return_batch_ids=False):
+    """post_parser.py:135-146 (+ the 1.1**scale of main.py:113, which the kernel applies to the
+    sampled rows only).  center_maps (B,1,64,64); params_maps either the NHWC tensor
+    (B,64,64,145) produced by RompNet.forward_nhwc or a (B,145,64,64) NCHW(-view) tensor.
+    Returns the reference's dict (device tensors) or None when nobody is detected."""
+    if params_maps.dim() == 4 and params_maps.shape[1] == 145 and params_maps.shape[-1] != 145:
+        params_maps = params_maps.permute(0, 2, 3, 1)          # free for RompNet's NCHW view
+    r = _parse(center_maps, params_maps, centermap_parser.conf_thresh, centermap_parser.max_person)
+    if r is None:
+        print('None person detected')
+        return (None, None) if return_batch_ids else None
+    thetas = r['smpl_thetas']
+    res = {
+        'cam': r['cam'], 'global_orient': thetas[:, :3].contiguous(), 'body_pose': thetas[:, 3:].contiguous(),
+        'smpl_betas': r['smpl_betas'], 'smpl_thetas': thetas,
+        'center_preds': r['center_preds'], 'center_confs': r['scores'].unsqueeze(1),
+    }
+    return (res, r['batch_ids']) if return_batch_ids else res
+
+
+def rot6D_to_angular(rot6D):
+    """utils.py:471-475 on device.  (N, J*6) -> (N, J*3)."""
+    lib = L.load()
+    x = rot6D.contiguous().float()
+    n = x.numel() // 6
+    out = torch.empty(n, 3, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(lib.romp_rot6d_to_aa(L.ptr(x), n, L.ptr(out), L.stream_ptr(x.device)))
+    return out.reshape(rot6D.shape[0], -1)
+
+
+def convert_cam_to_3d_trans(cams, weight=2.):
+    """utils.py:303-307 (kept as the reference's three-op torch expression; O(N) plumbing)."""
+    s, tx, ty = cams[:, 0], cams[:, 1], cams[:, 2]
+    return torch.stack([tx / s, ty / s, 1. / s], 1) * weight
+
+
+def estimate_translation_lsq(joints_3d, joints_2d, focal_length=443.4, img_size=(512., 512.)):
+    """Camera translation by linear least squares -- the reference's non-OpenCV branch
+    (estimate_translation_np, utils.py:350-389; taken when cv2.solvePnPRansac is unavailable,
+    utils.py:429-434).  joints_3d (N,K,3), joints_2d (N,K,2) numpy.  Host-side, O(N*K)."""
+    X = np.asarray(joints_3d, np.float64)
+    uv = np.asarray(joints_2d, np.float64)
+    N, K = X.shape[:2]
+    f = float(focal_length)
+    c = np.asarray(img_size, np.float64) / 2.
+    Q = np.zeros((N, 2 * K, 3))
+    Q[:, 0::2, 0] = f
+    Q[:, 1::2, 1] = f
+    Q[:, 0::2, 2] = c[0] - uv[:, :, 0]
+    Q[:, 1::2, 2] = c[1] - uv[:, :, 1]
+    rhs = np.zeros((N, 2 * K))
+    rhs[:, 0::2] = (uv[:, :, 0] - c[0]) * X[:, :, 2] - f * X[:, :, 0]
+    rhs[:, 1::2] = (uv[:, :, 1] - c[1]) * X[:, :, 2] - f * X[:, :, 1]
+    A = np.einsum('nki,nkj->nij', Q, Q)
+    b = np.einsum('nki,nk->ni', Q, rhs)
+    out = np.full((N, 3), -1.0, np.float32)
+    for i in range(N):
+        try:
+            out[i] = np.linalg.solve(A[i], b[i])
+        except np.linalg.LinAlgError:
+            pass
+    return out
+
+
+def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_offsets=None):
+    """post_parser.py:104-114.  pj2d / pj2d_org on device (csrc/parse.hip project_kernel);
+    `cam_trans` follows the reference's PnP step on the host (cv2.solvePnPRansac when OpenCV is
+    installed, else the reference's own least-squares fallback) -- a non-gated output."""
+    lib = L.load()
+    dev = j3d_preds.device
+    j = j3d_preds.contiguous().float()
+    cam = cam_preds.contiguous().float()
+    N, J = j.shape[:2]
+    pad = input2org_offsets if input2org_offsets is not None else torch.tensor([0., 512., 0., 512., 512., 512.])
+    pad_c = (C.c_float * 6)(*[float(v) for v in pad])
+    pj2d = torch.empty(N, J, 2, device=dev)
+    pj2d_org = torch.empty(N, J, 2, device=dev)
+    ct = torch.empty(N, 3, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.romp_project(L.ptr(j), N, J, L.ptr(cam), pad_c, L.ptr(pj2d), L.ptr(pj2d_org), L.ptr(ct),
+                                 L.stream_ptr(dev)))
+    j24 = j[:, :24].detach().cpu().numpy()
+    p24 = (pj2d[:, :24].detach().cpu().numpy() + 1) * 256            # post_parser.py:98
+    trans = None
+    try:
+        import cv2
+        camK = np.eye(3)
+        camK[0, 0] = camK[1, 1] = 443.4
+        camK[:2, 2] = 256
+        trans = np.zeros((N, 3), np.float32)
+        for i in range(N):
+            ret, rvec, tvec, inl = cv2.solvePnPRansac(j24[i], p24[i], camK, None, flags=cv2.SOLVEPNP_EPNP,
+                                                      reprojectionError=20, iterationsCount=100)
+            trans[i] = -1 if inl is None else tvec[:, 0]
+    except Exception:
+        trans = estimate_translation_lsq(j24, p24)
+    out = {'pj2d': pj2d, 'cam_trans': torch.from_numpy(trans).float().to(dev)}
+    if input2org_offsets is not None:
+        out['pj2d_org'] = pj2d_org
+    return out
+
+
+class SMPL_parser(nn.Module):
+    """post_parser.py:116-125."""
+
+    def __init__(self, model_path):
+        super(SMPL_parser, self).__init__()
+        self.smpl_model = SMPL(model_path)
+
+    def forward(self, outputs, root_align=False):
+        verts, joints, face = self.smpl_model(outputs['smpl_betas'], outputs['smpl_thetas'], root_align=root_align)
+        outputs.update({'verts': verts, 'joints': joints, 'smpl_face': face})
+        return outputs

@@ -1,0 +1,136 @@
+"""I/O helpers of the drop-in API -- mirror of the parts of simple_romp/romp/utils.py that the
+ROMP class touches (img_preprocess :26-30, padding_image :16-24, convert_tensor2numpy :32-41,
+ResultSaver :43-85, determine_device :734-739).  Host-side plumbing only; no hot-path maths.
+"""
+import os
+import os.path as osp
+
+import numpy as np
+import torch
+
+
+def padding_image(image):
+    """utils.py:16-24 -- zero-pad to a centred square; returns the pad info vector."""
+    h, w = image.shape[:2]
+    side = max(h, w)
+    pad_image = np.zeros((side, side, 3), dtype=np.uint8)
+    top, left = int((side - h) // 2), int((side - w) // 2)
+    bottom, right = int(top + h), int(left + w)
+    pad_image[top:bottom, left:right] = image
+    return pad_image, torch.Tensor([top, bottom, left, right, h, w])
+
+
+def _cubic_coeffs(fx, A=-0.75):
+    """OpenCV INTER_CUBIC kernel (a = -0.75) for fractional offset fx in [0,1)."""
+    c = np.empty(fx.shape + (4,), np.float64)
+    c[..., 0] = ((A * (fx + 1) - 5 * A) * (fx + 1) + 8 * A) * (fx + 1) - 4 * A
+    c[..., 1] = ((A + 2) * fx - (A + 3)) * fx * fx + 1
+    c[..., 2] = ((A + 2) * (1 - fx) - (A + 3)) * (1 - fx) * (1 - fx) + 1
+    c[..., 3] = 1. - c[..., 0] - c[..., 1] - c[..., 2]
+    return c
+
+
+def resize_bicubic_u8(img, size):
+    """Separable bicubic resize with OpenCV's sampling convention (pixel centres, a=-0.75,
+    replicated border); float arithmetic, rounded/saturated to uint8.  Used only when cv2 is
+    not installed (OpenCV's fixed-point rounding is not reproduced: pre-processing parity is
+    unpinned)."""
+    src = img.astype(np.float64)
+    for axis in (0, 1):
+        n_in = src.shape[axis]
+        scale = n_in / float(size)
+        f = (np.arange(size) + 0.5) * scale - 0.5
+        s0 = np.floor(f).astype(np.int64)
+        c = _cubic_coeffs(f - s0)
+        idx = np.clip(s0[:, None] + np.arange(-1, 3)[None], 0, n_in - 1)
+        g = np.take(src, idx, axis=axis)              # axis -> (size, 4)
+        shape = [1] * g.ndim
+        shape[axis], shape[axis + 1] = size, 4
+        src = (g * c.reshape(shape)).sum(axis=axis + 1)
+    return np.clip(np.rint(src), 0, 255).astype(np.uint8)
+
+
+def img_preprocess(image, input_size=512):
+    """utils.py:26-30: BGR->RGB, centred zero-pad to square, bicubic resize -> (1,S,S,3) float."""
+    image = np.ascontiguousarray(image[:, :, ::-1])
+    pad_image, image_pad_info = padding_image(image)
+    try:
+        import cv2
+        resized = cv2.resize(pad_image, (input_size, input_size), interpolation=cv2.INTER_CUBIC)
+    except ImportError:
+        resized = resize_bicubic_u8(pad_image, input_size)
+    return torch.from_numpy(resized)[None].float(), image_pad_info
+
+
+def convert_tensor2numpy(outputs, del_keys=('verts_camed', 'smpl_face', 'pj2d', 'verts_camed_org')):
+    """utils.py:32-41."""
+    for key in del_keys:
+        if key in outputs:
+            del outputs[key]
+    for key in list(outputs.keys()):
+        if isinstance(outputs[key], torch.Tensor):
+            outputs[key] = outputs[key].cpu().numpy()
+    return outputs
+
+
+def determine_device(gpu_id):
+    """utils.py:734-739."""
+    return torch.device('cuda:{}'.format(gpu_id)) if gpu_id != -1 else torch.device('cpu')
+
+
+class ResultSaver:
+    """utils.py:43-85 (npz saving; image writing needs cv2 and is skipped without it)."""
+
+    def __init__(self, mode='image', save_path=None, save_npz=True):
+        self.is_dir = len(osp.splitext(save_path)[1]) == 0
+        self.mode, self.save_path, self.save_npz = mode, save_path, save_npz
+        self.save_dir = save_path if self.is_dir else osp.dirname(save_path)
+        if self.mode in ['image', 'video']:
+            os.makedirs(self.save_dir, exist_ok=True)
+        if self.mode == 'video':
+            self.frame_save_paths = []
+
+    def __call__(self, outputs, input_path, prefix=None, img_ext='.png'):
+        if self.mode == 'video' or self.is_dir:
+            save_name = osp.basename(input_path)
+            save_path = osp.join(self.save_dir, osp.splitext(save_name)[0]) + img_ext
+        else:
+            save_path = self.save_path
+        if prefix is not None:
+            save_path = osp.splitext(save_path)[0] + f'_{prefix}' + osp.splitext(save_path)[1]
+        if outputs is not None and 'rendered_image' in outputs:
+            try:
+                import cv2
+                cv2.imwrite(save_path, outputs.pop('rendered_image'))
+            except ImportError:
+                outputs.pop('rendered_image')
+        if self.save_npz and outputs is not None:
+            np.savez(osp.splitext(save_path)[0] + '.npz', results=outputs)
+        if self.mode == 'video':
+            self.frame_save_paths.append(save_path)
+
+
+class WebcamVideoStream(object):
+    """utils.py:118-146 (threaded cv2.VideoCapture reader); needs OpenCV."""
+
+    def __init__(self, src=0):
+        import cv2
+        from threading import Thread
+        self._Thread = Thread
+        self.stream = cv2.VideoCapture(src)
+        (self.grabbed, self.frame) = self.stream.read()
+        self.stopped = False
+
+    def start(self):
+        self._Thread(target=self.update, args=(), daemon=True).start()
+        return self
+
+    def update(self):
+        while not self.stopped:
+            (self.grabbed, self.frame) = self.stream.read()
+
+    def read(self):
+        return self.frame
+
+    def stop(self):
+        self.stopped = True

@@ -1,0 +1,333 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the
+C ABI of libromp_hip.so, against the CPU oracle on identical seeded inputs and against the
+committed reference-generated fixtures in tests/golden/.
+
+Tolerances (float32 path):
+  * SMPL verts / joints on identical theta/beta: 1e-4 max-abs (the north-star gate; measured
+    float32 noise floor is ~3e-7)
+  * network maps: 1e-4 max-abs on center_maps / params_maps (reference fp32-vs-fp64 noise floor
+    is ~3e-6)
+  * parse: index sets bit-exact, scores bit-exact; axis-angle 2e-5 except near-pi rotations,
+    which are compared through the rotation matrix they encode.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import romp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    from romp_amd import lib
+    lib.load()                       # fail loudly if the HIP extension is missing
+    return torch.device('cuda:0')
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ------------------------------------------------------------------------------ SMPL
+@pytest.mark.parametrize('tag,nb', [('smpl', 10), ('smpla', 11)])
+def test_smpl_golden(dev, golden_dir, tag, nb):
+    from romp_amd.smpl import SMPL
+    g = _g(golden_dir, f'{tag}_n4.npz')
+    model = O.make_synthetic_smpl(seed=0, n_betas=nb)
+    smpl = SMPL(model, model_type=tag).to(dev)
+    for ra in (0, 1):
+        v, j, f = smpl(g['betas'], g['poses'], root_align=bool(ra))
+        assert v.shape == (4, 6890, 3) and j.shape == (4, 71, 3) and f.shape == (13776, 3)
+        ev = np.abs(v.cpu().numpy() - g[f'verts_ra{ra}']).max()
+        ej = np.abs(j.cpu().numpy() - g[f'joints_ra{ra}']).max()
+        print(f'{tag} root_align={ra}: verts max-abs {ev:.3e} joints {ej:.3e}')
+        assert ev < 1e-4 and ej < 1e-4
+
+
+@pytest.mark.parametrize('N', [1, 7, 64, 200])
+def test_smpl_vs_oracle(dev, N):
+    from romp_amd.smpl import SMPL
+    model = O.make_synthetic_smpl(seed=0)
+    smpl = SMPL(model).to(dev)
+    g = torch.Generator().manual_seed(0)
+    betas = torch.randn(N, 10, generator=g)
+    poses = 0.3 * torch.randn(N, 72, generator=g)
+    v, j, _ = smpl(betas, poses)
+    vo, jo, _ = O.smpl_forward(model, betas.numpy(), poses.numpy())
+    ev, ej = np.abs(v.cpu().numpy() - vo).max(), np.abs(j.cpu().numpy() - jo).max()
+    print(f'N={N}: verts {ev:.3e} joints {ej:.3e}')
+    assert ev < 1e-4 and ej < 1e-4
+
+
+def test_smpl_properties_full_size(dev):
+    """Config-2 worst case (32 images x 64 persons = 2048 meshes): size-independent properties.
+    (a) zero pose: verts == v_template + shapedirs.beta;  (b) a global rotation R0 about the root
+    joint rotates the mesh rigidly: verts' = R0 (verts - J0) + J0."""
+    from romp_amd.smpl import SMPL
+    model = O.make_synthetic_smpl(seed=0)
+    smpl = SMPL(model).to(dev)
+    N = 2048
+    g = torch.Generator().manual_seed(4)
+    betas = torch.randn(N, 10, generator=g)
+    v0, j0, _ = smpl(betas, torch.zeros(N, 72))
+    vs = model['v_template'][None] + torch.einsum('bl,mkl->bmk', betas, model['shapedirs'])
+    assert (v0.cpu() - vs).abs().max() < 2e-5
+    poses = 0.3 * torch.randn(N, 72, generator=g)
+    poses[:, :3] = 0
+    v1, j1, _ = smpl(betas, poses)
+    aa = torch.randn(N, 3, generator=g)
+    poses2 = poses.clone()
+    poses2[:, :3] = aa
+    v2, j2, _ = smpl(betas, poses2)
+    R0 = torch.from_numpy(O.batch_rodrigues(aa.numpy()))
+    J0 = j1[:, 0:1].cpu()
+    v_exp = torch.einsum('nij,nvj->nvi', R0, v1.cpu() - J0) + J0
+    assert (v2.cpu() - v_exp).abs().max() < 5e-5
+
+
+# ------------------------------------------------------------------------------ parse
+def test_rot6d_golden(dev, golden_dir):
+    from romp_amd.post_parser import rot6D_to_angular
+    g = _g(golden_dir, 'rot6d_cases.npz')
+    aa = rot6D_to_angular(torch.from_numpy(g['x']).to(dev)).cpu().numpy()
+    assert np.isfinite(aa).all()
+    err = np.abs(aa - g['aa']).max(1)
+    loose = err > 2e-5
+    print('rot6d: max err', err.max(), 'ill-conditioned cases', int(loose.sum()))
+    assert loose.sum() <= 12
+    np.testing.assert_allclose(O.batch_rodrigues(aa[loose]), O.batch_rodrigues(g['aa'][loose]), atol=2e-3)
+
+
+def _parse_inputs():
+    gen = torch.Generator().manual_seed(11)
+    cm = torch.rand(3, 1, 64, 64, generator=gen)
+    pm = torch.randn(3, 145, 64, 64, generator=gen)
+    cm[2] *= 0.2
+    return cm, pm
+
+
+def test_parse_golden(dev, golden_dir):
+    from romp_amd.post_parser import CenterMap, parsing_outputs
+    g = _g(golden_dir, 'parse_b3.npz')
+    cm, pm = _parse_inputs()
+    parser = CenterMap(float(g['thresh']))
+    out, bids = parsing_outputs(cm.to(dev), pm.permute(0, 2, 3, 1).contiguous().to(dev), parser, return_batch_ids=True)
+    assert np.array_equal(bids.cpu().numpy(), g['batch_ids'])
+    assert np.array_equal(out['center_preds'].cpu().numpy(), g['center_preds'])
+    assert out['center_preds'].dtype == torch.int64
+    assert np.array_equal(out['center_confs'].cpu().numpy(), g['center_confs'])
+    np.testing.assert_allclose(out['cam'].cpu().numpy(), g['cam'], rtol=2e-6, atol=1e-6)
+    assert np.array_equal(out['smpl_betas'].cpu().numpy(), g['smpl_betas'])
+    np.testing.assert_allclose(out['smpl_thetas'].cpu().numpy(), g['smpl_thetas'], atol=5e-5)
+    np.testing.assert_allclose(out['body_pose'].cpu().numpy(), g['body_pose'], atol=5e-5)
+    np.testing.assert_allclose(out['global_orient'].cpu().numpy(), g['global_orient'], atol=5e-5)
+    # NCHW view input gives the same answer
+    out2 = parsing_outputs(cm.to(dev), pm.to(dev), parser)
+    assert torch.equal(out2['smpl_thetas'], out['smpl_thetas'])
+    # nobody detected -> None (post_parser.py:138-140)
+    assert parsing_outputs(cm.to(dev) * 0.01, pm.to(dev), parser) is None
+
+
+@pytest.mark.parametrize('B,thresh', [(1, 0.9), (32, 0.5), (32, 0.995), (5, 0.0)])
+def test_parse_vs_oracle(dev, B, thresh):
+    """Includes the saturated case (64 persons in every image) and ties/plateaus."""
+    from romp_amd.post_parser import CenterMap, parsing_outputs
+    gen = torch.Generator().manual_seed(B)
+    cm = torch.rand(B, 1, 64, 64, generator=gen)
+    cm[0, 0, 10:13, 10:13] = 2.0                      # a 3x3 plateau: all 9 are maxima (exact equality)
+    cm[-1, 0, 40, 40] = 2.0                           # ties across positions
+    pm = torch.randn(B, 145, 64, 64, generator=gen)
+    ref = O.parsing_outputs(cm.numpy(), pm.numpy(), thresh)
+    out, bids = parsing_outputs(cm.to(dev), pm.to(dev), CenterMap(thresh), return_batch_ids=True)
+    assert np.array_equal(bids.cpu().numpy(), ref['batch_ids'])
+    assert np.array_equal(out['center_preds'].cpu().numpy(), ref['center_preds'])
+    assert np.array_equal(out['center_confs'].cpu().numpy()[:, 0], ref['scores'])
+    np.testing.assert_allclose(out['cam'].cpu().numpy(), ref['cam'], rtol=2e-6, atol=1e-6)
+    d = np.abs(out['smpl_thetas'].cpu().numpy() - ref['smpl_thetas']).reshape(-1, 3).max(1)
+    assert (d > 5e-5).mean() < 0.01                   # near-pi rotations are ill-conditioned
+
+
+# ------------------------------------------------------------------------------ conv layers
+CONV_CASES = [
+    # (Cin, Cout, k, stride, H, relu, residual)
+    (32, 32, 3, 1, 128, True, True), (64, 64, 3, 1, 64, True, False), (128, 128, 3, 1, 32, True, True),
+    (256, 256, 3, 1, 16, True, True), (256, 32, 3, 1, 128, True, False), (64, 64, 3, 2, 256, True, False),
+    (256, 64, 3, 2, 128, True, False), (32, 64, 3, 2, 128, False, False), (32, 32, 3, 2, 128, True, False),
+    (64, 128, 3, 2, 64, False, False), (128, 256, 3, 2, 32, False, False), (32, 256, 3, 2, 32, False, False),
+    (40, 192, 3, 2, 128, True, False),
+    (64, 64, 1, 1, 128, True, False), (64, 256, 1, 1, 128, False, False), (256, 64, 1, 1, 128, True, True),
+    (64, 32, 1, 1, 64, False, False), (128, 32, 1, 1, 32, False, False), (256, 128, 1, 1, 16, False, False),
+    (64, 142, 1, 1, 64, False, False), (64, 1, 1, 1, 64, False, False), (64, 3, 1, 1, 64, False, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'c%d_%d_k%d_s%d_h%d' % c[:5])
+@pytest.mark.parametrize('B', [1, 3])
+def test_conv_layer(dev, case, B):
+    """One fused conv+BN(+res)(+ReLU) layer through romp_conv_forward vs torch CPU conv2d."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act
+    cin, cout, k, s, H, relu, use_res = case
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k + s + H)
+    x = torch.randn(B, H, H, cin, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    Ho = (H + 2 * (k // 2) - k) // s + 1
+    res = torch.randn(B, Ho, Ho, cout, generator=g) if use_res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, None, stride=s, padding=k // 2)
+    ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2)
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    P = Program(dev)
+    xa = Act(0, cin, H, H, cin)
+    P.buf_floats.append(cin * H * H)
+    ra = None
+    if res is not None:
+        P.buf_floats.append(cout * Ho * Ho)
+        ra = Act(1, cout, Ho, Ho, cout)
+    P.conv('t', xa, [w], [scale], [shift], k, s, relu, res=ra)
+    op = P.ops[0]
+    xd, rd = x.to(dev), (res.to(dev) if res is not None else None)
+    lib = L.load()
+    for mode in (0, 1):
+        out = torch.full((B, Ho, Ho, cout), float('nan'), device=dev)
+        L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), L.ptr(rd), L.ptr(out), B, mode, L.stream_ptr(dev)))
+        torch.cuda.synchronize()
+        err = (out.cpu() - ref).abs().max().item()
+        print(f'mode {mode}: max-abs err {err:.3e} (ref absmax {ref.abs().max():.2f})')
+        assert err < 2e-5, f'mode {mode} err {err}'
+
+
+# ------------------------------------------------------------------------------ network
+@pytest.fixture(scope='module')
+def net0(dev):
+    from romp_amd.net import RompNet
+    return RompNet(O.make_romp_state_dict(0), dev, max_batch=4)
+
+
+def test_net_golden(dev, golden_dir, net0):
+    g = _g(golden_dir, 'romp_net_b1.npz')
+    img = O.make_images(1, seed=1).to(dev)
+    for mode in (1, 0):
+        net0.set_mode(mode)
+        cm, pm = net0(img)
+        assert cm.shape == (1, 1, 64, 64) and pm.shape == (1, 145, 64, 64)
+        ec = np.abs(cm.cpu().numpy() - g['center_maps']).max()
+        p = pm[0].reshape(145, -1).cpu().numpy()
+        ep = np.abs(p[:, g['sample_pos']] - g['params_samples']).max()
+        es = np.abs(p.astype(np.float64).sum(1) - g['params_chan_sum']).max()
+        print(f'mode {mode}: center max-abs {ec:.3e} params max-abs {ep:.3e} chan-sum {es:.3e}')
+        assert ec < 1e-4 and ep < 1e-4 and es < 5e-2
+    net0.set_mode(0)
+
+
+def test_net_vs_oracle_batch(dev, net0):
+    sd = O.make_romp_state_dict(0)
+    img = O.make_images(3, seed=5)
+    cm_o, pm_o = O.romp_net_forward(sd, img)
+    cm, pm = net0(img.to(dev))
+    ec = (cm.cpu() - cm_o).abs().max().item()
+    ep = (pm.cpu() - pm_o).abs().max().item()
+    print(f'B=3 center {ec:.3e} params {ep:.3e}')
+    assert ec < 1e-4 and ep < 1e-4
+    # batch position independence: image 2 alone == image 2 in the batch
+    cm1, pm1 = net0(img[2:3].to(dev))
+    assert (cm1 - cm[2:3]).abs().max().item() < 2e-5 and (pm1 - pm[2:3]).abs().max().item() < 2e-5
+    # hipGraph replay gives the same maps as eager launches
+    net0.set_graph(True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x = img.to(dev)
+        c1, p1 = net0.forward_nhwc(x)
+        c2, p2 = net0.forward_nhwc(x, c1.clone(), p1.clone())
+    s.synchronize()
+    net0.set_graph(False)
+    assert torch.equal(c1.unsqueeze(1), cm) and torch.equal(c2, c1)
+
+
+def test_net_full_batch_properties(dev):
+    """BASELINE config 2 size (B=32): images repeated inside the batch must give identical maps
+    (no cross-image leakage, tile/batch indexing correct at full size), and a permuted batch must
+    give permuted outputs."""
+    from romp_amd.net import RompNet
+    net = RompNet(O.make_romp_state_dict(0), dev, max_batch=32)
+    base = O.make_images(4, seed=2).to(dev)
+    idx = torch.arange(32) % 4
+    cm, pm = net.forward_nhwc(base[idx])
+    for r in range(4, 32):
+        assert torch.equal(cm[r], cm[r % 4]) and torch.equal(pm[r], pm[r % 4])
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(0))
+    cm2, pm2 = net.forward_nhwc(base[idx][perm])
+    assert torch.equal(cm2, cm[perm]) and torch.equal(pm2, pm[perm])
+    assert torch.isfinite(pm).all()
+
+
+# ------------------------------------------------------------------------------ end to end
+def test_romp_api_end_to_end(dev):
+    """romp.ROMP(settings)(image) dict contract + parity of every gated output
+    with the oracle pipeline on the same synthetic weights."""
+    import romp_amd
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh = 0, 1.25
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    smpl_model = O.make_synthetic_smpl(0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+    rs = np.random.RandomState(0)
+    image = rs.randint(0, 256, (360, 640, 3)).astype(np.uint8)          # BGR, non-square
+    out = model(image)
+    assert out is not None
+    N = out['cam'].shape[0]
+    assert N >= 1
+    shapes = {'cam': (N, 3), 'global_orient': (N, 3), 'body_pose': (N, 69), 'smpl_betas': (N, 10),
+              'smpl_thetas': (N, 72), 'center_preds': (N, 2), 'center_confs': (N, 1), 'cam_trans': (N, 3),
+              'verts': (N, 6890, 3), 'joints': (N, 71, 3), 'pj2d_org': (N, 71, 2)}
+    for k, shp in shapes.items():
+        assert isinstance(out[k], np.ndarray) and out[k].shape == shp, k
+    assert set(out.keys()) == set(shapes.keys())
+    assert out['center_preds'].dtype == np.int64 and out['verts'].dtype == np.float32
+    # oracle pipeline on the same pre-processed tensor
+    from romp_amd.utils import img_preprocess
+    inp, pad = img_preprocess(image)
+    cm, pm = O.romp_net_forward(sd, inp)
+    ref = O.parsing_outputs(cm.numpy(), pm.numpy(), settings.center_thresh)
+    assert np.array_equal(out['center_preds'], ref['center_preds'])
+    np.testing.assert_allclose(out['smpl_thetas'], ref['smpl_thetas'], atol=2e-4)
+    np.testing.assert_allclose(out['cam'], ref['cam'], atol=1e-4)
+    vo, jo, _ = O.smpl_forward(smpl_model, out['smpl_betas'], out['smpl_thetas'])    # identical theta/beta
+    assert np.abs(out['verts'] - vo).max() < 1e-4 and np.abs(out['joints'] - jo).max() < 1e-4
+    pj = O.project_to_org_image(O.batch_orth_proj(jo, out['cam']), pad.numpy())
+    np.testing.assert_allclose(out['pj2d_org'], pj, atol=2e-2)
+    # nobody above threshold -> None
+    settings.center_thresh = 50.0
+    model2 = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+    assert model2(image) is None
+
+
+def test_forward_batch_matches_oracle(dev):
+    import romp_amd
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh = 0, 1.3
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    smpl_model = O.make_synthetic_smpl(0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+    img = O.make_images(3, seed=8)
+    out, bids = model.forward_batch(img.to(dev))
+    cm, pm = O.romp_net_forward(sd, img)
+    ref = O.parsing_outputs(cm.numpy(), pm.numpy(), settings.center_thresh)
+    assert np.array_equal(bids.cpu().numpy(), ref['batch_ids'])
+    assert np.array_equal(out['center_preds'].cpu().numpy(), ref['center_preds'])
+    vo, jo, _ = O.smpl_forward(smpl_model, ref['smpl_betas'], ref['smpl_thetas'])
+    ev = np.abs(out['verts'].cpu().numpy() - vo).max()
+    print('end-to-end verts max-abs vs oracle pipeline', ev, 'persons', len(ref['batch_ids']))
+    assert ev < 1e-3
