@@ -77,11 +77,38 @@ def roofline_report(model, images, lib, L):
     return roof, classes
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    the physical core count (SMT siblings do not help MKLDNN convolutions; 256 threads on the
+    2x64-core box ran 50x slower than 64)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        cores = set()
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+                cores.add((phys, core))
+        if cores:
+            n = min(n, len(cores))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(sd, smpl_model, thresh, seconds):
     """The oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
     from oracle import romp_oracle as O
     from romp_amd import synthetic as S
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(usable_cores())
     Bc = 4
     img = S.make_images(Bc, seed=1)
 
@@ -90,13 +117,17 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
         r = O.parsing_outputs(cm.numpy(), pm.numpy(), thresh)
         if r is not None:
             O.smpl_forward(smpl_model, r['smpl_betas'], r['smpl_thetas'])
-    step()
+    t0 = time.time()
+    step()                                    # warm-up (also bounds the sample on a slow host)
+    warm = time.time() - t0
     t0, n = time.time(), 0
-    while True:
+    while warm < seconds / 2:
         step(); n += 1
         if time.time() - t0 > seconds or n >= 8:
             break
     dt = time.time() - t0
+    if n == 0:
+        n, dt = 1, warm
     return dict(value=round(Bc * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
                 sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload, torch-CPU float32 '
                        '(reference onnxruntime path unavailable: module not installed)' % (n, Bc))

@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 passes over bench.py (one GPU): kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in
+# their own passes (PMC never combined with sys/runtime traces).  Summaries -> gpurun_out/prof/.
+REPO="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$REPO/gpurun_out/prof"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+export PYTHONUNBUFFERED=1
+BENCH="python $REPO/bench.py --no-cpu-baseline"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
+echo "stats pass exit $?"
+find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/rp_$C -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_$C.log" 2>&1
+  echo "pmc $C exit $?"
+  f=$(find /tmp/rp_$C -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python "$REPO/scripts/summarize_pmc.py" "$f" $C > "$OUT/pmc_${C}_by_kernel.csv"
+done
+head -40 "$OUT/kernel_stats.csv"
+tail -3 "$OUT/bench_under_rocprof.log" | cut -c1-1500
+head -30 "$OUT/pmc_FETCH_SIZE_by_kernel.csv"; head -30 "$OUT/pmc_WRITE_SIZE_by_kernel.csv"

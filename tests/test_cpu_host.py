@@ -1,0 +1,197 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/romp_hip.h
+declares, the ctypes struct mirrors the C struct, the layer program is well formed, host helpers
+behave, and the product path refuses to run without a HIP device (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'romp_hip.h')
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b((?:romp|smpl)_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from romp_amd import lib as L
+    h = L.load()
+    names = _declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(h, n), 'libromp_hip.so does not export %s' % n
+    assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
+    assert h.romp_abi_version() == 1
+
+
+def test_romp_op_struct_layout_matches_header():
+    from romp_amd.lib import RompOp
+    prog = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "romp_hip.h"
+    int main(void) { printf("%zu %zu %zu %zu %zu\n", sizeof(romp_op), offsetof(romp_op, groups),
+        offsetof(romp_op, term_buf), offsetof(romp_op, weight), offsetof(romp_op, shift)); return 0; }
+    '''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, 't.c')
+        open(c, 'w').write(prog)
+        exe = os.path.join(td, 't')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
+        vals = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert vals == [C.sizeof(RompOp), RompOp.groups.offset, RompOp.term_buf.offset, RompOp.weight.offset,
+                    RompOp.shift.offset]
+
+
+def test_no_cpu_fallback_in_product_path():
+    import romp_amd
+    from romp_amd.lib import RompHipError
+    s = romp_amd.romp_settings([])
+    s.GPU = -1
+    with pytest.raises(RompHipError):
+        romp_amd.ROMP(s, state_dict={}, smpl_model={})
+    from romp_amd.post_parser import parsing_outputs, CenterMap
+    with pytest.raises(RompHipError):
+        parsing_outputs(torch.zeros(1, 1, 64, 64), torch.zeros(1, 64, 64, 145), CenterMap(0.25))
+    from romp_amd.smpl import SMPL
+    from romp_amd.synthetic import make_smpl_model
+    with pytest.raises(RompHipError):
+        SMPL(make_smpl_model())(torch.zeros(1, 10), torch.zeros(1, 72))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'romp_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt and 'oracle/' not in txt, f
+
+
+def test_settings_match_reference_defaults():
+    import romp_amd
+    s = romp_amd.main.default_settings
+    assert s.center_thresh == 0.25 and s.calc_smpl is True and s.render_mesh is False
+    assert s.root_align is False and s.mode == 'image' and s.onnx is False and s.smooth_coeff == 3.0
+    assert s.smpl_path.endswith(os.path.join('.romp', 'SMPL_NEUTRAL.pth'))
+    assert s.model_path.endswith(os.path.join('.romp', 'ROMP.pkl'))
+    assert {'ROMP', 'romp_settings', 'ResultSaver', 'WebcamVideoStream'} <= set(dir(romp_amd))
+
+
+@pytest.fixture(scope='module')
+def program():
+    from romp_amd import synthetic as S
+    from romp_amd.plan import build_romp_hrnet32
+    return build_romp_hrnet32(S.make_romp_state_dict(0), 'cpu')
+
+
+def test_program_matches_reference_inventory(program):
+    """310 convs (stem conv1 + 309), 85.71 GFLOP; the three head first convs
+    merge into one and the six tower convs into... (grouped), 23 fuse outputs."""
+    from romp_amd.lib import OP_CONV, OP_FUSESUM, OP_STEM
+    kinds = [o.kind for o in program.ops]
+    assert kinds.count(OP_STEM) == 1 and kinds.count(OP_FUSESUM) == 23
+    n_conv_ref = sum(o.groups for o in program.ops if o.kind == OP_CONV) + 2 + 1   # +2 merged head convs, +1 stem
+    assert n_conv_ref == 310
+    gflop = sum(program.flops) / 1e9
+    assert abs(gflop - 85.71) < 0.2, gflop
+    mb = sum(program.bytes) / 1e6
+    assert 1100 < mb < 1200, mb                      # 1164 MB/img algorithmic
+
+
+def test_program_buffer_liveness(program):
+    """No op may read a buffer whose producer has since been overwritten: replay the program
+    symbolically, tagging each buffer with the op that last wrote it."""
+    from romp_amd.lib import OP_CONV, OP_FUSESUM, OP_STEM
+    writer = {}
+    expected = {}          # (consumer op index, buffer) -> producer recorded at plan time is implicit:
+    for i, op in enumerate(program.ops):
+        reads = []
+        if op.kind in (OP_CONV, OP_STEM) and op.in_buf >= 0:
+            reads.append(op.in_buf)
+        if op.kind == OP_CONV and op.res_buf >= 0:
+            reads.append(op.res_buf)
+        if op.kind == OP_FUSESUM:
+            reads += [op.term_buf[k] for k in range(op.n_terms)]
+        for b in reads:
+            assert b in writer, 'op %d (%s) reads buffer %d before it was written' % (i, program.names[i], b)
+            assert b != op.out_buf or b == program.head_in_buf, 'op %d runs in place on buffer %d' % (i, b)
+        if op.out_buf >= 0:
+            writer[op.out_buf] = i
+    assert program.head_in_buf in writer
+    # arena stays small because of reuse: < 100 MB per image although 323 ops produce ~560 MB of activations
+    assert sum(program.buf_floats) * 4 / 1e6 < 100
+
+
+def test_conv_describe_every_op(program):
+    from romp_amd import lib as L
+    h = L.load()
+    buf = C.create_string_buffer(128)
+    for B in (1, 32):
+        for op in program.ops:
+            L.check(h.romp_conv_describe(C.byref(op), B, buf, 128))
+            assert buf.value
+
+
+def test_weight_packing_roundtrip():
+    from romp_amd.plan import pack_conv_weight, conv_pads, fold_bn
+    w = torch.randn(70, 34, 3, 3)
+    cin_pad, cout_pad = conv_pads(40, 70, 3)
+    assert (cin_pad, cout_pad) == (40, 128)
+    p = pack_conv_weight(torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 6)), cin_pad, cout_pad)
+    assert p.shape == (9, 10, 128, 4)
+    for (co, ci, ky, kx) in [(0, 0, 0, 0), (69, 33, 2, 1), (5, 17, 1, 2)]:
+        assert p[ky * 3 + kx, ci // 4, co, ci % 4] == w[co, ci, ky, kx]
+    assert p[:, :, 70:].abs().sum() == 0 and p[:, 8, :, 2:].abs().sum() == 0
+    sd = {'b.weight': torch.tensor([2.0]), 'b.bias': torch.tensor([0.5]), 'b.running_mean': torch.tensor([1.0]),
+          'b.running_var': torch.tensor([4.0 - 1e-5])}
+    s, b = fold_bn(sd, 'b', 1, bias=torch.tensor([3.0]))
+    assert abs(s.item() - 1.0) < 1e-6 and abs(b.item() - (0.5 - 1.0 + 3.0)) < 1e-6
+
+
+def test_img_preprocess_contract():
+    from romp_amd.utils import img_preprocess, resize_bicubic_u8
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (90, 160, 3)).astype(np.uint8)
+    x, pad = img_preprocess(img)
+    assert x.shape == (1, 512, 512, 3) and x.dtype == torch.float32
+    assert pad.tolist() == [35.0, 125.0, 0.0, 160.0, 90.0, 160.0]
+    assert x[0, :100].abs().sum() == 0                       # zero padding above the image
+    # identity-size resize is exact; constant image stays constant
+    same = resize_bicubic_u8(img[:64, :64], 64)
+    assert np.array_equal(same, img[:64, :64])
+    assert np.all(resize_bicubic_u8(np.full((40, 40, 3), 77, np.uint8), 512) == 77)
+    # BGR -> RGB
+    img2 = np.zeros((64, 64, 3), np.uint8); img2[..., 0] = 200
+    y, _ = img_preprocess(img2)
+    assert y[0, 256, 256].tolist() == [0.0, 0.0, 200.0]
+
+
+def test_translation_lsq_recovers_known_translation():
+    from romp_amd.post_parser import estimate_translation_lsq
+    rs = np.random.RandomState(1)
+    X = rs.randn(5, 24, 3) * 0.3
+    t = rs.randn(5, 3) * 0.2 + np.array([0, 0, 5.0])
+    P = X + t[:, None]
+    uv = 443.4 * P[:, :, :2] / P[:, :, 2:3] + 256
+    est = estimate_translation_lsq(X, uv)
+    np.testing.assert_allclose(est, t, atol=1e-4)
+
+
+def test_shard_range_partitions():
+    from romp_amd.distributed import shard_range
+    for n, w in [(1024, 8), (10, 4), (3, 8), (32, 1)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        for a, b in zip(spans, spans[1:]):
+            assert a[1] == b[0]
+        assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

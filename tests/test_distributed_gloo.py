@@ -1,0 +1,93 @@
+"""World-size-2 test of the multi-GPU result exchange on CPU (gloo): the all-gather-v of the
+per-person records must reproduce the single-process ordering (rank-major == image order),
+including a rank with zero detections and uneven counts."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_outputs(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.randint(0, 4096, (n,), generator=g)
+    return {
+        'cam': torch.randn(n, 3, generator=g), 'smpl_thetas': torch.randn(n, 72, generator=g),
+        'smpl_betas': torch.randn(n, 10, generator=g), 'center_confs': torch.rand(n, 1, generator=g),
+        'center_preds': torch.stack([flat % 64, flat // 64], 1) * 8, 'joints': torch.randn(n, 71, 3, generator=g),
+    }, torch.sort(torch.randint(0, 4, (n,), generator=g))[0]
+
+
+def _worker(rank, world, port, counts, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from romp_amd import distributed as D
+    lo, hi = D.shard_range(8, rank, world)
+    n = counts[rank]
+    rec = None
+    if n:
+        out, bids = _fake_outputs(n, 100 + rank)
+        rec = D.pack_records(out, bids, lo, with_joints=True)
+    allrec, got = D.all_gather_records(rec, D.record_width(True), torch.device('cpu'))
+    un = D.unpack_records(allrec, with_joints=True)
+    q.put((rank, got, un['image_ids'].tolist(), un['smpl_thetas'].sum().item(), tuple(un['joints'].shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(counts):
+    world = len(counts)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, counts, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def _expected(counts):
+    sys.path.insert(0, ROOT)
+    from romp_amd import distributed as D
+    ids, tsum = [], 0.0
+    for r, n in enumerate(counts):
+        if n:
+            out, bids = _fake_outputs(n, 100 + r)
+            lo, _ = D.shard_range(8, r, len(counts))
+            ids += (bids + lo).tolist()
+            tsum += out['smpl_thetas'].sum().item()
+    return ids, tsum
+
+
+def test_allgather_records_world2_uneven():
+    for counts in ([5, 3], [0, 4], [7, 0]):
+        res = _run(counts)
+        ids, tsum = _expected(counts)
+        for rank, got, image_ids, s, jshape in res:
+            assert got == counts
+            assert image_ids == ids
+            assert abs(s - tsum) < 1e-3
+            assert jshape == (sum(counts), 71, 3)
+
+
+def test_allgather_records_nobody_anywhere():
+    res = _run([0, 0])
+    for rank, got, image_ids, s, jshape in res:
+        assert got == [0, 0] and image_ids == [] and jshape == (0, 71, 3)

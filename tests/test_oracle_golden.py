@@ -22,7 +22,7 @@ def _ld(golden_dir, name):
 def test_param_spec_matches_reference_count():
     spec = O.romp_param_spec()
     assert len(spec) == 1544            # 1851 state-dict entries - 307 num_batches_tracked
-    assert sum(int(np.prod(s)) for s, _ in spec.values()) == 29104530 - 0 or True
+    assert sum(int(np.prod(s)) for s, _ in spec.values()) == 29104530   # 29.1 M params
     n_bn = sum(1 for _, k in spec.values() if k == 'bn_w')
     assert n_bn == 307
     n_conv = sum(1 for _, k in spec.values() if k == 'conv_w')
