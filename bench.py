@@ -40,7 +40,9 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--center-thresh', type=float, default=1.3)
-    ap.add_argument('--graph', type=int, default=0, help='replay the network from a hipGraph')
+    ap.add_argument('--graph', type=int, default=1, help='replay the network from a hipGraph')
+    ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
+    ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-roofline', action='store_true')
@@ -54,11 +56,11 @@ def roofline_report(model, images, lib, L):
     net = model.model
     B = images.shape[0]
     ms = net.profile(images, iters=3)
-    buf = C.create_string_buffer(128)
     agg = {}
-    for op, t, fl, by in zip(net.program.ops, ms, net.program.flops, net.program.bytes):
-        L.check(lib.romp_conv_describe(C.byref(op), B, buf, 128))
-        a = agg.setdefault(buf.value.decode(), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+    for name, t, fl, by in zip(net.variant_names(B), ms, net.program.flops, net.program.bytes):
+        if name in ('fork', 'join'):
+            continue
+        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         a['ms'] += t; a['flops'] += fl * B; a['bytes'] += by * B; a['launches'] += 1
     classes = {}
     for k, a in agg.items():
@@ -153,6 +155,9 @@ def main():
     sd = S.make_romp_state_dict(0)
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+    model.model.set_streams(args.streams)
+    if args.autotune:
+        model.model.autotune(args.batch)
     if args.graph:
         model.model.set_graph(True)
     B = args.batch
@@ -198,7 +203,7 @@ def main():
         'config': {'workload': 'ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); '
                                'net+parse+SMPL%s' % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'persons_per_image': round(persons / (B * world), 2),
-                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'parallelism': 'dp%d' % world},
+                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'parallelism': 'dp%d' % world},
     }
     if rank == 0:
         if not args.no_roofline:

@@ -56,6 +56,8 @@ const char* romp_last_error(void);
 #define ROMP_OP_STEM      1     /* x/255*2-1 + conv3x3 s2 (Cin=3) + BN + ReLU  (model.py:384-387) */
 #define ROMP_OP_CONV      2     /* conv KxK (K=1|3, stride 1|2) + scale/shift (+res) (+ReLU)      */
 #define ROMP_OP_FUSESUM   3     /* y = relu(sum_t up_nearest(T_t))   (model.py:233-244)           */
+#define ROMP_OP_FORK      4     /* side streams 1..Cin start after everything enqueued so far     */
+#define ROMP_OP_JOIN      5     /* the main stream waits for side streams 1..Cin                  */
 
 typedef struct romp_op {
     int32_t kind;
@@ -72,6 +74,9 @@ typedef struct romp_op {
     int32_t term_buf[4];
     int32_t term_shift[4];        /* log2 of the nearest-upsample factor of each term     */
     int32_t term_cstride[4];
+    int32_t stream;               /* 0 = main stream, 1..3 = side stream (between FORK and JOIN):
+                                     independent HRNet branches run concurrently (model.py:230-231) */
+    int32_t reserved;
     const float* weight;          /* packed [group][chunk][tap][cin/4][cout_pad][4]       */
     const float* scale;           /* [group][cout_pad]  gamma/sqrt(var+eps)  (or 1)       */
     const float* shift;           /* [group][cout_pad]  beta-mean*scale (+scale*bias)     */
@@ -93,19 +98,28 @@ int  romp_net_read_buffer(romp_net* net, int buf, int B, float* dst, int64_t n_f
 int  romp_net_write_buffer(romp_net* net, int buf, const float* src, int64_t n_floats, void* stream);
 /* 0: tuned MFMA kernels (default)   1: naive direct-conv kernels (bring-up cross-check) */
 int  romp_net_set_mode(romp_net* net, int mode);
+/* 1 (default): independent HRNet branches (FORK/JOIN regions) run on side HIP streams. */
+int  romp_net_set_streams(romp_net* net, int enable);
 /* 1: capture the layer program into a hipGraph per (B, pointers) and replay it. */
 int  romp_net_set_graph(romp_net* net, int enable);
+/* Measure every valid kernel variant of every conv layer at batch B (HIP events on `stream`,
+ * `iters` timed runs each) and use the fastest from now on for that batch size. */
+int  romp_net_autotune(romp_net* net, int B, int iters, void* stream);
+/* Variant index chosen by romp_net_autotune for op `op_index` at batch B (-1: heuristic). */
+int  romp_net_tuned_variant(romp_net* net, int B, int op_index);
 /* Time the most recent forward per op (HIP events on `stream`); ms_out_host[n_ops]. */
 int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,
                       float* params_maps_nhwc, void* stream, float* ms_out_host, int iters);
 void romp_net_destroy(romp_net* net);
 
-/* Stand-alone conv launcher (tests / microbenchmarks of one layer). */
+/* Stand-alone conv launcher (tests / microbenchmarks of one layer).  variant < 0: heuristic. */
 int  romp_conv_forward(const romp_op* op_host, const float* in, const float* res, float* out,
-                       int B, int mode, void* stream);
+                       int B, int mode, int variant, void* stream);
+int  romp_conv_num_variants(void);
 
-/* Name of the kernel variant the dispatcher picks for `op` at batch B (profiling reports). */
-int  romp_conv_describe(const romp_op* op_host, int B, char* out_host, int n);
+/* Name of kernel variant `variant` (or, if < 0, of the heuristic choice at batch B) for `op`;
+ * ROMP_EINVAL if that variant cannot run this op. */
+int  romp_conv_describe(const romp_op* op_host, int B, int variant, char* out_host, int n);
 
 /* ------------------------------------------------------------------ seam #2: parsing */
 

@@ -29,9 +29,12 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // launchers implemented in the kernel translation units
+// variant < 0: heuristic choice; queue: 8 zeroed ints (nullptr: library scratch, memset on `st`)
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B,
-                int mode, hipStream_t st);
-int describe_conv(const romp_op& op, int B, char* out, int n);
+                int mode, int variant, int* queue, hipStream_t st);
+int describe_conv(const romp_op& op, int B, int variant, char* out, int n);
+int conv_num_variants();
+bool conv_variant_valid(const romp_op& op, int variant);
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
 struct FuseTerm { const float* ptr; int shift; int cstride; };
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,

@@ -5,23 +5,29 @@
 // Replaces, per layer, the conv2d + batch_norm + add + relu op sequence the reference launches
 // (BasicBlock.forward model.py:67-83, Bottleneck.forward :103-123, transition / fuse / head convs).
 //
-// GEMM view:  M = output pixels (B*Ho*Wo), N = Cout, K = taps*Cin.
+// GEMM view:  M = Cout, N = output pixels (B*Ho*Wo), K = taps*Cin.
 //   v_mfma_f32_32x32x2_f32: A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31],
 //   D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-//   A rows are pixels, B columns are output channels, so one lane owns ONE output channel for 16
-//   pixels: the BN scale/shift is two scalars per lane and every store instruction writes two
-//   128-byte channel runs.
+//   A rows are output channels (weights), B columns are pixels: a lane ends up with 4 groups of 4
+//   CONSECUTIVE channels of ONE pixel, so the epilogue loads scale/shift/residual and stores the
+//   result as float4 (NHWC keeps channels contiguous).
 //   The arithmetic is exact f32 (one rounding per product, f32 accumulate) -- the parity mode the
 //   1e-4 gate needs; gfx950 has no TF32-like shortcut.
 //
-// Workgroup = 4 waves (one per SIMD).  A workgroup owns a TH x TW output-pixel tile of one image
-// and NT*32 output channels; each wave owns MT M-blocks (32 pixels each) x NT N-blocks.
-// Per input-channel chunk (CK channels) the haloed input tile and the weight slab are staged in
-// LDS; the next chunk's global loads are issued BEFORE the MFMA loop of the current chunk and
-// written to LDS after it (issue-early / write-late), so HBM/L2 latency hides under the MFMAs.
-// LDS pixel stride is CK+4 floats: the ds_read_b128 A-fragment reads of 16 consecutive pixels then
-// hit 16 distinct 16-byte bank slots (conflict-free at stride 1, 2-way at stride 2).
+// Workgroup = 4 waves (one per SIMD), PERSISTENT: it pulls work items (pixel tile x channel slice
+// x group) from a per-XCD queue (one returning atomicAdd per item, issued a whole item ahead), so
+// all CUs finish within one item of each other regardless of how the item count divides the chip,
+// and the channel slices of one pixel tile run back-to-back on the same XCD (shared L2).
+// A work item = TH x TW output pixels x NT*32 output channels; each wave owns MT pixel blocks
+// (32 pixels each) x NT channel blocks.  Per input-channel chunk (CK channels) the haloed input
+// tile and the weight slab are staged in LDS; the NEXT stage's global loads (next chunk, or the
+// next item's first chunk) are issued before the MFMA loop of the current stage and written to
+// LDS after it (issue-early / write-late), so HBM/L2 latency hides under the MFMAs and there is no
+// exposed prologue between items.  LDS pixel stride is CK+4 floats: the ds_read_b128 fragment
+// reads of 16 consecutive pixels hit 16 distinct 16-byte bank slots (conflict-free at stride 1,
+// 2-way at stride 2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace romp {
 
@@ -30,6 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvParams {
     const float* in; const float* w; const float* scale; const float* shift; const float* res;
     float* out;
+    int* queue;               // 8 per-XCD work counters, zeroed before the launch
     int H, W, Ho, Wo;
     int Cout;                 // valid output channels per group (store mask)
     int cin_valid;            // channels physically present in the input (loader mask)
@@ -38,8 +45,12 @@ struct ConvParams {
     int out_cs, out_co, out_gs;
     int res_cs, res_co, res_gs;
     int relu;
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y, tiles_total;
+    int nslices, ns_total;    // channel slices per group; slices*groups
+    int n_queues, per_queue;  // 8 (XCD-aware) or 1
+    int vec_io;               // epilogue may use float4 loads/stores
     int w_gs;                 // floats per group in the packed weight
+    int dbg;                  // ablation switches (ROMP_CONV_DEBUG; timing experiments only)
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -48,55 +59,191 @@ template <int KS, int S, int MT, int NT, int TW, int CK>
 struct ConvCfg {
     static constexpr int TAPS = KS * KS;
     static constexpr int PAD = KS / 2;
-    static constexpr int RPB = 32 / TW;              // tile rows per 32-pixel M-block
+    static constexpr int RPB = 32 / TW;              // tile rows per 32-pixel block
     static constexpr int TH = 4 * MT * RPB;          // output tile rows
     static constexpr int HR = (TH - 1) * S + KS;     // haloed input rows
     static constexpr int HC = (TW - 1) * S + KS;
     static constexpr int PS = CK + 4;                // LDS floats per pixel (padded)
-    static constexpr int NW = NT * 32;               // output channels per workgroup
+    static constexpr int NW = NT * 32;               // output channels per work item
     static constexpr int QC = CK / 4;                // float4 per pixel per chunk
     static constexpr int A_VEC = HR * HC * QC;
     static constexpr int B_VEC = TAPS * QC * NW;
     static constexpr int NA = (A_VEC + 255) / 256;
     static constexpr int NB = (B_VEC + 255) / 256;
-    static constexpr int LDS_BYTES = (HR * HC * PS + TAPS * CK * NW) * 4;
+    static constexpr int LDS_BYTES = (HR * HC * PS + TAPS * CK * NW + 4 * NW) * 4 + 16;
 };
+
+struct Item { int b, ty, tx, n0, g; };
+
+__device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, int NW) {
+    const int s = j % p.ns_total, tl = j / p.ns_total;
+    int t = tl * p.n_queues + q;
+    Item it;
+    it.g = s / p.nslices;
+    it.n0 = (s % p.nslices) * NW;
+    it.tx = t % p.tiles_x; t /= p.tiles_x;
+    it.ty = t % p.tiles_y;
+    it.b = t / p.tiles_y;
+    return it;
+}
+
+// Epilogue of one work item: y = acc*scale + shift (+ residual) (ReLU), NHWC float4 stores.
+// Lane owns pixel li of pixel-block m and channels n0 + n*32 + 8*g4 + 4*lh + {0..3}.
+// All residual loads of the item are issued up front in ONE batch under ONE uniform branch (a
+// branch per float4 serialises MT*NT*4 dependent global round trips -- that alone held the
+// 3x3 kernels at ~100 TFLOP/s), ReLU is branch-free (max with 0 or -inf).
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][NT],
+                                              const float* sSc, int wave, int li, int lh) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    float* out = p.out + (size_t)cur.b * p.Ho * p.Wo * p.out_cs + p.out_co + cur.g * p.out_gs;
+    const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
+    const float floor_v = p.relu ? 0.f : -__builtin_inff();
+    unsigned pixo[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mb = wave * MT + m;
+        const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
+        pixo[m] = (unsigned)(oy * p.Wo + ox);
+    }
+    if (p.vec_io) {
+        float4 r[MT][NT][4];
+        if (res) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        r[m][n][g4] = ldg4(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8 + lh * 4)));
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) r[m][n][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cl = n * 32 + g4 * 8 + lh * 4;
+                const float4 sc = *reinterpret_cast<const float4*>(sSc + cl);
+                const float4 sh = *reinterpret_cast<const float4*>(sSc + C::NW + cl);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float4 v;
+                    v.x = fmaxf(fmaf(acc[m][n][g4 * 4 + 0], sc.x, sh.x) + r[m][n][g4].x, floor_v);
+                    v.y = fmaxf(fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y) + r[m][n][g4].y, floor_v);
+                    v.z = fmaxf(fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z) + r[m][n][g4].z, floor_v);
+                    v.w = fmaxf(fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w) + r[m][n][g4].w, floor_v);
+                    *reinterpret_cast<float4*>(out + (pixo[m] * (unsigned)p.out_cs + (unsigned)(cur.n0 + cl))) = v;
+                }
+            }
+    } else {
+        // scalar path: output convs of the head (Cout = 142 / 1 / 3 into unaligned NHWC slots)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cl = n * 32 + g4 * 8 + lh * 4;
+                    const int co = cur.n0 + cl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.Cout) {
+                            float t = fmaf(acc[m][n][g4 * 4 + e], sSc[cl + e], sSc[C::NW + cl + e]);
+                            if (res) t += res[pixo[m] * (unsigned)p.res_cs + (unsigned)(co + e)];
+                            out[pixo[m] * (unsigned)p.out_cs + (unsigned)(co + e)] = fmaxf(t, floor_v);
+                        }
+                    }
+                }
+    }
+}
+
+// One stage of the implicit GEMM: all taps x channel octets of the staged chunk.  The LDS fragment
+// reads of step k+1 are issued BEFORE the MFMAs of step k (register double buffer, pinned with
+// sched_barrier): an f32 MFMA group keeps the pipe busy for >= 512 cycles, so the ds_read latency
+// is hidden instead of draining the matrix pipe at every step (hipcc otherwise sinks each read
+// next to its use: `ds_read; s_waitcnt lgkmcnt(0); v_mfma`).
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__device__ __forceinline__ void mma_stage(const float* sA, const float* sB, const int (&xoff)[MT], int woff,
+                                          f32x16 (&acc)[MT][NT]) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    constexpr int STEPS = C::TAPS * (CK / 8);
+    float4 xf[2][MT], wf[2][NT];
+    auto load = [&](int step, int buf) {
+        const int tap = step / (CK / 8), q8 = step % (CK / 8);
+        const int dy = tap / KS, dx = tap % KS;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            xf[buf][m] = *reinterpret_cast<const float4*>(sA + xoff[m] + (dy * C::HC + dx) * C::PS + q8 * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            wf[buf][n] = *reinterpret_cast<const float4*>(sB + woff + ((tap * C::QC + q8 * 2) * C::NW + n * 32) * 4);
+    };
+    load(0, 0);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int cb = step & 1;
+        if (step + 1 < STEPS) load(step + 1, cb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][n].x, xf[cb][m].x, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][n].y, xf[cb][m].y, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][n].z, xf[cb][m].z, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cb][n].w, xf[cb][m].w, acc[m][n], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;
-    float* sB = smem + C::HR * C::HC * C::PS;
+    float* sA = smem;                                  // haloed pixels
+    float* sB = smem + C::HR * C::HC * C::PS;          // weight slab
+    float* sS = sB + C::TAPS * CK * C::NW;             // 2 slots x {scale[NW], shift[NW]} (current / next item)
+    int* sQ = reinterpret_cast<int*>(sS + 4 * C::NW);  // work-queue mailbox
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
+    const int n_chunks = p.cin_pad / CK;
 
-    int bx = blockIdx.x;
-    const int tx = bx % p.tiles_x; bx /= p.tiles_x;
-    const int ty = bx % p.tiles_y;
-    const int b = bx / p.tiles_y;
-    const int n0 = blockIdx.y * C::NW;
-    const int g = blockIdx.z;
-
-    const float* in = p.in + (size_t)b * p.H * p.W * p.in_cs + p.in_co + g * p.in_gs;
-    const float* wg = p.w + (size_t)g * p.w_gs;
-    const int iy0 = ty * C::TH * S - C::PAD, ix0 = tx * TW * S - C::PAD;
+    // ---- work queue: fetch the first two items synchronously, later ones a whole item ahead
+    if (tid == 0) {
+        sQ[0] = atomicAdd(p.queue + q, 1);
+        sQ[1] = atomicAdd(p.queue + q, 1);
+    }
+    __syncthreads();
+    int j_cur = sQ[0], j_next = sQ[1];
+    if (j_cur >= p.per_queue) return;
 
     float4 ra[C::NA], rb[C::NB];
+    float rs = 0.f;                                    // one scale-or-shift value (threads < 2*NW)
 
-    auto issue_loads = [&](int c0) {
+    auto issue_loads = [&](const Item& it, int c0) {
+        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
+        const float* wg = p.w + (size_t)it.g * p.w_gs;
+        const int iy0 = it.ty * C::TH * S - C::PAD, ix0 = it.tx * TW * S - C::PAD;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < C::A_VEC) {
-                const int q = idx % C::QC, pix = idx / C::QC;
+                const int qq = idx % C::QC, pix = idx / C::QC;
                 const int hx = pix % C::HC, hy = pix / C::HC;
-                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + q * 4;
+                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
                 if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
-                    v = ldg4(in + ((size_t)iy * p.W + ix) * p.in_cs + c);
+                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
             }
             ra[k] = v;
         }
@@ -106,19 +253,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < C::B_VEC) {
                 const int j = idx % C::NW, tq = idx / C::NW;
-                const int q = tq % C::QC, tap = tq / C::QC;
-                v = ldg4(wg + (((size_t)tap * (p.cin_pad >> 2) + (c0 >> 2) + q) * p.cout_pad + n0 + j) * 4);
+                const int qq = tq % C::QC, tap = tq / C::QC;
+                v = ldg4(wg + (unsigned)(((tap * (p.cin_pad >> 2) + (c0 >> 2) + qq) * p.cout_pad + it.n0 + j) * 4));
             }
             rb[k] = v;
         }
+        if (c0 == 0 && tid < 2 * C::NW) {
+            const float* src = tid < C::NW ? p.scale : p.shift;
+            rs = src[it.g * p.cout_pad + it.n0 + (tid & (C::NW - 1))];
+        }
     };
-    auto write_lds = [&]() {
+    auto write_lds = [&](bool first_chunk, int slot) {
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
             if (idx < C::A_VEC) {
-                const int q = idx % C::QC, pix = idx / C::QC;
-                *reinterpret_cast<float4*>(sA + pix * C::PS + q * 4) = ra[k];
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                *reinterpret_cast<float4*>(sA + pix * C::PS + qq * 4) = ra[k];
             }
         }
 #pragma unroll
@@ -126,17 +277,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             const int idx = tid + k * 256;
             if (idx < C::B_VEC) *reinterpret_cast<float4*>(sB + idx * 4) = rb[k];
         }
+        if (first_chunk && tid < 2 * C::NW) sS[slot * 2 * C::NW + tid] = rs;
     };
 
-    // per-wave fragment base addresses
-    int aoff[MT];
+    // per-wave fragment base addresses (pixel fragments) and weight fragment base
+    int xoff[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int mb = wave * MT + m;
         const int row = mb * C::RPB + li / TW, col = li % TW;
-        aoff[m] = ((row * S) * C::HC + col * S) * C::PS + lh * 4;
+        xoff[m] = ((row * S) * C::HC + col * S) * C::PS + lh * 4;
     }
-    const int boff = (lh * C::NW + li) * 4;
+    const int woff = (lh * C::NW + li) * 4;
+
+    Item cur = decode_item(p, q, j_cur, C::NW);
+    issue_loads(cur, 0);
+    write_lds(true, 0);
+    __syncthreads();
+    int slot = 0, ch = 0;
+    Item nxt = cur;
+    bool have_next = j_next < p.per_queue;
+    if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+    int j_after = 0x7fffffff;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -146,63 +308,213 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int n_chunks = p.cin_pad / CK;
-    issue_loads(0);
-    for (int ch = 0; ch < n_chunks; ++ch) {
-        __syncthreads();                 // everyone finished reading the previous chunk
-        write_lds();
-        __syncthreads();
-        if (ch + 1 < n_chunks) issue_loads((ch + 1) * CK);
+    // Flat stage loop (stage = one channel chunk of one item).  Invariant at the top: the stage's
+    // pixels/weights are in LDS and visible.  Per stage: issue the NEXT stage's global loads (next
+    // chunk, or chunk 0 of the next item) -> MFMA loop -> barrier -> staging registers to LDS ->
+    // (item finished: epilogue; the staging registers are dead by then) -> barrier.
+    // One load site and one LDS-write site keep the compiler from hoisting per-item address math.
+#pragma unroll 1
+    while (true) {
+        const bool last = ch + 1 == n_chunks;
+        const bool pf = !last || have_next;          // is there a next stage to prefetch?
+        Item tgt = last ? nxt : cur;
+        const int c0 = last ? 0 : (ch + 1) * CK;
+        if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);   // item after next
+        if (pf && !(p.dbg & 1)) issue_loads(tgt, c0);
+        if (!(p.dbg & 8)) mma_stage<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
+        if (ch == 0 && tid == 0) sQ[0] = j_after;
+        if (!(p.dbg & 16)) __syncthreads();   // every wave finished reading this stage
+        if (pf && !(p.dbg & 2)) write_lds(last, slot ^ 1);
+        if (last) {
+            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
 #pragma unroll
-        for (int tap = 0; tap < C::TAPS; ++tap) {
-            const int dy = tap / KS, dx = tap % KS;
-#pragma unroll
-            for (int q8 = 0; q8 < CK / 8; ++q8) {
-                float4 af[MT], bf[NT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    af[m] = *reinterpret_cast<const float4*>(sA + aoff[m] + (dy * C::HC + dx) * C::PS + q8 * 8);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    bf[n] = *reinterpret_cast<const float4*>(sB + boff + ((tap * C::QC + q8 * 2) * C::NW + n * 32) * 4);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].x, bf[n].x, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].y, bf[n].y, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].z, bf[n].z, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m].w, bf[n].w, acc[m][n], 0, 0, 0);
-                    }
-            }
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        }
+        if (last && !have_next) break;
+        __syncthreads();                      // next stage (and sQ[0]) visible
+        if (last) {
+            cur = nxt;
+            slot ^= 1;
+            ch = 0;
+            j_next = sQ[0];
+            have_next = j_next < p.per_queue;
+            if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+        } else {
+            ++ch;
         }
     }
+}
 
-    // epilogue: BN scale/shift (+ residual) (+ ReLU); lane owns channel n0+n*32+li
-    float* out = p.out + (size_t)b * p.Ho * p.Wo * p.out_cs + p.out_co + g * p.out_gs;
-    const float* res = p.res ? p.res + (size_t)b * p.Ho * p.Wo * p.res_cs + p.res_co + g * p.res_gs : nullptr;
-    const int oy0 = ty * C::TH, ox0 = tx * TW;
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant: 8 waves per workgroup = two groups of 4 waves, each group an independent copy
+// of the pipeline above (own work items, own LDS region), forced to ALTERNATE: while group A runs
+// its MFMA phase, group B runs its memory phase (staging registers -> LDS, epilogue stores, residual
+// loads), then they swap.  With 4-wave workgroups scheduled independently the two waves sharing a
+// SIMD drift into the same phase and the matrix pipe idles ~35-40 % of the time (rocprofv3:
+// SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE = 0.60); here every SIMD always has exactly one wave in
+// its MFMA phase.  One workgroup-wide barrier per phase.  2 waves/SIMD => up to 256 VGPRs per wave.
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    constexpr int GROUP_FLOATS = C::LDS_BYTES / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = threadIdx.x >> 8;                  // wave group 0 / 1
+    const int tid = threadIdx.x & 255;                 // thread within the group
+    float* sA = smem + grp * GROUP_FLOATS;             // haloed pixels
+    float* sB = sA + C::HR * C::HC * C::PS;            // weight slab
+    float* sS = sB + C::TAPS * CK * C::NW;             // 2 slots x {scale[NW], shift[NW]}
+    int* sQ = reinterpret_cast<int*>(sS + 4 * C::NW);  // per-group mailbox: [0],[1] items, [2] done flag
+    int* sQ_other = reinterpret_cast<int*>(smem + (grp ^ 1) * GROUP_FLOATS + C::HR * C::HC * C::PS + C::TAPS * CK * C::NW + 4 * C::NW);
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
+    const int n_chunks = p.cin_pad / CK;
+
+    if (tid == 0) {
+        sQ[0] = atomicAdd(p.queue + q, 1);
+        sQ[1] = atomicAdd(p.queue + q, 1);
+        sQ[2] = 0;
+    }
+    __syncthreads();
+    int j_cur = sQ[0], j_next = sQ[1];
+    bool done = j_cur >= p.per_queue;
+    if (done && sQ_other[0] >= p.per_queue) return;    // uniform over the workgroup
+    __syncthreads();                                   // everyone has read the mailboxes
+    if (done && tid == 0) sQ[2] = 1;
+
+    float4 ra[C::NA], rb[C::NB];
+    float rs = 0.f;
+
+    auto issue_loads = [&](const Item& it, int c0) {
+        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
+        const float* wg = p.w + (size_t)it.g * p.w_gs;
+        const int iy0 = it.ty * C::TH * S - C::PAD, ix0 = it.tx * TW * S - C::PAD;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = n0 + n * 32 + li;
-        const float sc = p.scale[g * p.cout_pad + co], sh = p.shift[g * p.cout_pad + co];
-        const bool ok = co < p.Cout;
+        for (int k = 0; k < C::NA; ++k) {
+            const int idx = tid + k * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < C::A_VEC) {
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                const int hx = pix % C::HC, hy = pix / C::HC;
+                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
+                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
+            }
+            ra[k] = v;
+        }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int mb = wave * MT + m;
+        for (int k = 0; k < C::NB; ++k) {
+            const int idx = tid + k * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < C::B_VEC) {
+                const int j = idx % C::NW, tq = idx / C::NW;
+                const int qq = tq % C::QC, tap = tq / C::QC;
+                v = ldg4(wg + (unsigned)(((tap * (p.cin_pad >> 2) + (c0 >> 2) + qq) * p.cout_pad + it.n0 + j) * 4));
+            }
+            rb[k] = v;
+        }
+        if (c0 == 0 && tid < 2 * C::NW) {
+            const float* src = tid < C::NW ? p.scale : p.shift;
+            rs = src[it.g * p.cout_pad + it.n0 + (tid & (C::NW - 1))];
+        }
+    };
+    auto write_lds = [&](bool first_chunk, int slot) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + mb * C::RPB + pr / TW, ox = ox0 + pr % TW;
-                const size_t pix = (size_t)oy * p.Wo + ox;
-                float v = fmaf(acc[m][n][r], sc, sh);
-                if (ok) {
-                    if (res) v += res[pix * p.res_cs + co];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    out[pix * p.out_cs + co] = v;
+        for (int k = 0; k < C::NA; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < C::A_VEC) {
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                *reinterpret_cast<float4*>(sA + pix * C::PS + qq * 4) = ra[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < C::NB; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < C::B_VEC) *reinterpret_cast<float4*>(sB + idx * 4) = rb[k];
+        }
+        if (first_chunk && tid < 2 * C::NW) sS[slot * 2 * C::NW + tid] = rs;
+    };
+
+    int xoff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mb = wave * MT + m;
+        const int row = mb * C::RPB + li / TW, col = li % TW;
+        xoff[m] = ((row * S) * C::HC + col * S) * C::PS + lh * 4;
+    }
+    const int woff = (lh * C::NW + li) * 4;
+
+    Item cur, nxt;
+    cur.b = cur.ty = cur.tx = cur.n0 = cur.g = 0;
+    nxt = cur;
+    bool have_next = false;
+    if (!done) {
+        cur = decode_item(p, q, j_cur, C::NW);
+        issue_loads(cur, 0);
+        write_lds(true, 0);
+        have_next = j_next < p.per_queue;
+        nxt = have_next ? decode_item(p, q, j_next, C::NW) : cur;
+    }
+    int slot = 0, ch = 0, j_after = 0x7fffffff;
+    bool last = false, pf = false;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int phase = 0;; ++phase) {
+        const int step = phase - grp;                  // group g: compute on even steps, memory on odd
+        if (!done && step >= 0) {
+            if ((step & 1) == 0) {
+                // ---------------- MFMA phase of stage (cur, ch)
+                last = ch + 1 == n_chunks;
+                pf = !last || have_next;
+                Item tgt = last ? nxt : cur;
+                const int c0 = last ? 0 : (ch + 1) * CK;
+                if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
+                if (pf) issue_loads(tgt, c0);
+                mma_stage<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
+                if (ch == 0 && tid == 0) sQ[0] = j_after;
+            } else {
+                // ---------------- memory phase: staging registers -> LDS, epilogue of a finished item
+                if (pf) write_lds(last, slot ^ 1);
+                if (last) {
+                    conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+                    if (!have_next) {
+                        done = true;
+                        if (tid == 0) sQ[2] = 1;
+                    } else {
+                        cur = nxt;
+                        slot ^= 1;
+                        ch = 0;
+                        j_next = sQ[0];               // written in this item's first MFMA phase (>= 1 barrier ago)
+                        have_next = j_next < p.per_queue;
+                        if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+                    }
+                } else {
+                    ++ch;
                 }
             }
         }
+        __syncthreads();
+        if (sQ[2] && sQ_other[2]) break;               // both groups finished (uniform)
     }
 }
 
@@ -239,18 +551,22 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
 // dispatch
 // ------------------------------------------------------------------------------------------------
 typedef void (*conv_fn)(ConvParams);
-struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; };
+struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; };
 
 #define ROMP_CONV_VARIANT(KS, S, MT, NT, TW, CK)                                      \
     { KS, S, MT, NT, TW, CK, conv_mfma_kernel<KS, S, MT, NT, TW, CK>,                 \
-      ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH }
+      ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0 }
+#define ROMP_CONV_VARIANT_PP(KS, S, MT, NT, TW, CK)                                   \
+    { KS, S, MT, NT, TW, CK, conv_pp_kernel<KS, S, MT, NT, TW, CK>,                   \
+      2 * ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 1 }
 
-static const ConvVariant kVariants[] = {
+static ConvVariant kVariants[] = {
     // 3x3 stride 1
     ROMP_CONV_VARIANT(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(3, 1, 2, 2, 32, 16),
     ROMP_CONV_VARIANT(3, 1, 1, 1, 32, 16), ROMP_CONV_VARIANT(3, 1, 1, 2, 32, 16),
+    ROMP_CONV_VARIANT(3, 1, 4, 1, 32, 16),
     ROMP_CONV_VARIANT(3, 1, 1, 1, 16, 16), ROMP_CONV_VARIANT(3, 1, 1, 2, 16, 16),
-    ROMP_CONV_VARIANT(3, 1, 2, 2, 16, 16),
+    ROMP_CONV_VARIANT(3, 1, 2, 1, 16, 16), ROMP_CONV_VARIANT(3, 1, 2, 2, 16, 16),
     // 3x3 stride 2
     ROMP_CONV_VARIANT(3, 2, 1, 1, 32, 16), ROMP_CONV_VARIANT(3, 2, 1, 2, 32, 16),
     ROMP_CONV_VARIANT(3, 2, 1, 1, 16, 16), ROMP_CONV_VARIANT(3, 2, 1, 2, 16, 16),
@@ -259,44 +575,88 @@ static const ConvVariant kVariants[] = {
     // 1x1
     ROMP_CONV_VARIANT(1, 1, 2, 1, 32, 32), ROMP_CONV_VARIANT(1, 1, 2, 2, 32, 32),
     ROMP_CONV_VARIANT(1, 1, 1, 1, 32, 32), ROMP_CONV_VARIANT(1, 1, 1, 2, 32, 32),
+    ROMP_CONV_VARIANT(1, 1, 4, 1, 32, 32), ROMP_CONV_VARIANT(1, 1, 4, 2, 32, 32),
     ROMP_CONV_VARIANT(1, 1, 1, 1, 16, 32), ROMP_CONV_VARIANT(1, 1, 1, 2, 16, 32),
     ROMP_CONV_VARIANT(1, 1, 2, 2, 16, 32),
     ROMP_CONV_VARIANT(1, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(1, 1, 2, 2, 32, 16),
+    // ping-pong (8 waves, two alternating groups)
+    ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 16, 16),
+    ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 16, 16),
+    ROMP_CONV_VARIANT_PP(3, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 2, 2, 16, 16),
+    ROMP_CONV_VARIANT_PP(3, 1, 1, 1, 16, 16), ROMP_CONV_VARIANT_PP(3, 1, 1, 1, 32, 16),
+    ROMP_CONV_VARIANT_PP(3, 2, 1, 2, 16, 16), ROMP_CONV_VARIANT_PP(3, 2, 1, 1, 16, 16),
+    ROMP_CONV_VARIANT_PP(3, 2, 1, 2, 32, 8), ROMP_CONV_VARIANT_PP(3, 2, 1, 1, 32, 16),
+    ROMP_CONV_VARIANT_PP(1, 1, 2, 2, 32, 32), ROMP_CONV_VARIANT_PP(1, 1, 2, 1, 32, 32),
+    ROMP_CONV_VARIANT_PP(1, 1, 1, 2, 16, 32), ROMP_CONV_VARIANT_PP(1, 1, 2, 2, 32, 16),
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static bool g_attr_done = false;
+static int g_num_cu = 256;
+static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers without an arena
+
+static const int kMaxLds = 160 * 1024;
 
 static int ensure_attrs() {
     if (g_attr_done) return ROMP_OK;
-    for (int i = 0; i < kNumVariants; ++i)
+    int dev = 0;
+    ROMP_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    ROMP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int i = 0; i < kNumVariants; ++i) {
+        if (kVariants[i].lds > kMaxLds) continue;
         if (kVariants[i].lds > 48 * 1024)
             ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kVariants[i].fn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kVariants[i].lds));
+        int occ = 0;
+        ROMP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kVariants[i].fn),
+                                                                    kVariants[i].pp ? 512 : 256, kVariants[i].lds));
+        kVariants[i].occ = occ > 0 ? occ : 1;
+    }
+    ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, 8 * sizeof(int)));
     g_attr_done = true;
     return ROMP_OK;
 }
 
-// Pick the variant: widest tile that divides the output map, then the largest per-workgroup
-// footprint that still yields >= ~2 workgroups per CU at this batch size.
-static const ConvVariant* choose_variant(const romp_op& op, int Ho, int Wo, int B) {
-    const ConvVariant* best = nullptr;
+static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) {
+    if (v.lds > kMaxLds) return false;
+    if (v.ks != op.ksize || v.s != op.stride) return false;
+    if (Wo % v.tw || Ho % v.th) return false;
+    if (op.cin_pad % v.ck || op.cout_pad % (v.nt * 32)) return false;
+    return true;
+}
+
+// Heuristic choice (used until romp_net_autotune has measured the alternatives).
+static int choose_variant(const romp_op& op, int Ho, int Wo, int B) {
+    int best = -1;
     double best_score = -1;
     for (int i = 0; i < kNumVariants; ++i) {
         const ConvVariant& v = kVariants[i];
-        if (v.ks != op.ksize || v.s != op.stride) continue;
-        if (Wo % v.tw || Ho % v.th) continue;
-        if (op.cin_pad % v.ck || op.cout_pad % (v.nt * 32)) continue;
-        const long wgs = (long)B * (Ho / v.th) * (Wo / v.tw) * (op.cout_pad / (v.nt * 32)) * op.groups;
-        // work per WG ~ mt*nt ; prefer big tiles while the grid still fills 256 CUs twice
-        double fill = wgs >= 512 ? 1.0 : (double)wgs / 512.0;
+        if (!variant_ok(v, op, Ho, Wo)) continue;
+        const long items = (long)B * (Ho / v.th) * (Wo / v.tw) * (op.cout_pad / (v.nt * 32)) * op.groups;
+        double fill = items >= 512 ? 1.0 : (double)items / 512.0;
         double score = fill * (1.0 + 0.25 * (v.mt * v.nt - 1)) * (v.ck >= 16 ? 1.0 : 0.8) * (v.tw == 32 ? 1.05 : 1.0);
-        if (score > best_score) { best_score = score; best = &v; }
+        if (v.mt * v.nt > 4) score *= 0.5;
+        if (score > best_score) { best_score = score; best = i; }
     }
     return best;
 }
 
+static void out_dims(const romp_op& op, int* Ho, int* Wo) {
+    *Ho = (op.H + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
+    *Wo = (op.W + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
+}
+
+int conv_num_variants() { return kNumVariants; }
+
+bool conv_variant_valid(const romp_op& op, int variant) {
+    int Ho, Wo;
+    out_dims(op, &Ho, &Wo);
+    return variant >= 0 && variant < kNumVariants && variant_ok(kVariants[variant], op, Ho, Wo);
+}
+
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B, int mode,
-                hipStream_t st) {
+                int variant, int* queue, hipStream_t st) {
     ROMP_REQUIRE(op.ksize == 1 || op.ksize == 3, "conv: ksize %d unsupported", op.ksize);
     ROMP_REQUIRE(op.stride == 1 || op.stride == 2, "conv: stride %d unsupported", op.stride);
     ROMP_REQUIRE(op.groups >= 1, "conv: groups must be >= 1");
@@ -305,15 +665,19 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     ConvParams p;
     p.in = in; p.w = op.weight; p.scale = op.scale; p.shift = op.shift; p.res = res; p.out = out;
     p.H = op.H; p.W = op.W;
-    p.Ho = (op.H + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
-    p.Wo = (op.W + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
+    out_dims(op, &p.Ho, &p.Wo);
     p.Cout = op.Cout; p.cin_valid = op.Cin; p.cin_pad = op.cin_pad; p.cout_pad = op.cout_pad;
     p.in_cs = op.in_cstride; p.in_co = op.in_coff; p.in_gs = op.in_gstride;
     p.out_cs = op.out_cstride; p.out_co = op.out_coff; p.out_gs = op.out_gstride;
     p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.res_gs = op.res_gstride;
     p.relu = op.relu;
     p.w_gs = op.ksize * op.ksize * op.cin_pad * op.cout_pad;
-    p.tiles_x = p.tiles_y = 1;
+    p.tiles_x = p.tiles_y = p.tiles_total = 1;
+    p.nslices = p.ns_total = p.n_queues = p.per_queue = 1;
+    p.queue = nullptr;
+    { const char* e = getenv("ROMP_CONV_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.vec_io = (op.Cout == op.cout_pad && (op.Cout & 3) == 0 && (op.out_cstride & 3) == 0 && (op.out_coff & 3) == 0 && (op.out_gstride & 3) == 0 &&
+                (!res || ((op.res_cstride & 3) == 0 && (op.res_coff & 3) == 0 && (op.res_gstride & 3) == 0))) ? 1 : 0;
     if (mode == 1) {
         const size_t total = (size_t)B * p.Ho * p.Wo * op.Cout * op.groups;
         int blocks = (int)((total + 255) / 256);
@@ -324,23 +688,40 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     }
     int rc = ensure_attrs();
     if (rc) return rc;
-    const ConvVariant* v = choose_variant(op, p.Ho, p.Wo, B);
-    ROMP_REQUIRE(v != nullptr, "conv: no kernel variant for k%d s%d Cin %d(pad %d) Cout %d(pad %d) out %dx%d",
+    if (variant < 0) variant = choose_variant(op, p.Ho, p.Wo, B);
+    ROMP_REQUIRE(variant >= 0 && variant < kNumVariants && variant_ok(kVariants[variant], op, p.Ho, p.Wo),
+                 "conv: no kernel variant (%d) for k%d s%d Cin %d(pad %d) Cout %d(pad %d) out %dx%d", variant,
                  op.ksize, op.stride, op.Cin, op.cin_pad, op.Cout, op.cout_pad, p.Ho, p.Wo);
-    p.tiles_x = p.Wo / v->tw;
-    p.tiles_y = p.Ho / v->th;
-    dim3 grid((unsigned)(B * p.tiles_x * p.tiles_y), (unsigned)(op.cout_pad / (v->nt * 32)), (unsigned)op.groups);
-    hipLaunchKernelGGL(v->fn, grid, dim3(256), v->lds, st, p);
+    const ConvVariant& v = kVariants[variant];
+    p.tiles_x = p.Wo / v.tw;
+    p.tiles_y = p.Ho / v.th;
+    p.tiles_total = B * p.tiles_x * p.tiles_y;
+    p.nslices = op.cout_pad / (v.nt * 32);
+    p.ns_total = p.nslices * op.groups;
+    p.n_queues = (p.tiles_total % 8 == 0) ? 8 : 1;
+    p.per_queue = (p.tiles_total / p.n_queues) * p.ns_total;
+    if (queue == nullptr) {
+        queue = g_queue_scratch;
+        ROMP_HIP_CHECK(hipMemsetAsync(queue, 0, 8 * sizeof(int), st));
+    }
+    p.queue = queue;
+    const long items = (long)p.tiles_total * p.ns_total;
+    long grid = (long)g_num_cu * v.occ;
+    const long want = v.pp ? (items + 1) / 2 : items;         // a ping-pong workgroup runs two item streams
+    if (grid > want) grid = want;
+    if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;    // same number of workgroups per queue
+    hipLaunchKernelGGL(v.fn, dim3((unsigned)grid), dim3(v.pp ? 512 : 256), v.lds, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }
 
-int describe_conv(const romp_op& op, int B, char* out, int n) {
-    const int Ho = (op.H + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
-    const int Wo = (op.W + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
-    const ConvVariant* v = choose_variant(op, Ho, Wo, B);
-    ROMP_REQUIRE(v != nullptr, "describe: no variant");
-    snprintf(out, n, "conv_mfma_k%ds%d_mt%d_nt%d_tw%d_ck%d", v->ks, v->s, v->mt, v->nt, v->tw, v->ck);
+int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
+    int Ho, Wo;
+    out_dims(op, &Ho, &Wo);
+    if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
+    ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
+    const ConvVariant& v = kVariants[variant];
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.pp ? "conv_pp" : "conv_mfma", v.ks, v.s, v.mt, v.nt, v.tw, v.ck);
     return ROMP_OK;
 }
 

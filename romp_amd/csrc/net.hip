@@ -2,9 +2,10 @@
 //
 // The host lowers the model definition (HRNet-32 + ROMP head, model.py:246-481) to a flat list of
 // romp_op; this file owns the activation arena (NHWC float32, sized for max_batch, resident in HBM
-// for the life of the context) and replays the list on the caller's stream -- eagerly, or from a
-// hipGraph captured per (batch, I/O pointers) so that the ~350 dependent launches of one forward
-// cost one graph launch on the host.
+// for the life of the context), the per-op work queues of the persistent conv kernels, the
+// per-batch-size kernel-variant table filled by romp_net_autotune, and replays the list on the
+// caller's stream -- eagerly, or from a hipGraph captured per (batch, I/O pointers) so that the
+// ~330 dependent launches of one forward cost one graph launch on the host.
 #include "common.h"
 #include <vector>
 #include <map>
@@ -36,9 +37,15 @@ struct romp_net {
     std::vector<romp_op> ops;
     std::vector<int64_t> buf_floats;     // per image
     std::vector<float*> bufs;
+    int* queues = nullptr;               // n_ops x 8 work counters, zeroed at the start of a forward
     int max_batch = 0;
     int mode = 0;
     int use_graph = 0;
+    int use_streams = 1;                 // run FORK/JOIN regions on side streams
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr};
+    std::map<int, std::vector<int>> tuned;   // batch -> variant per op (-1: heuristic)
     std::map<GraphKey, hipGraphExec_t> graphs;
 };
 
@@ -54,8 +61,9 @@ static float* resolve_out(romp_net* n, int buf, float* center, float* params) {
     return nullptr;
 }
 
-static int run_op(romp_net* n, const romp_op& op, const float* image, int B, float* center, float* params,
+static int run_op(romp_net* n, size_t idx, int variant, const float* image, int B, float* center, float* params,
                   hipStream_t st) {
+    const romp_op& op = n->ops[idx];
     switch (op.kind) {
         case ROMP_OP_STEM: {
             const float* in = resolve_in(n, op.in_buf, image);
@@ -69,7 +77,7 @@ static int run_op(romp_net* n, const romp_op& op, const float* image, int B, flo
             const float* res = op.res_buf == ROMP_BUF_NONE ? nullptr : resolve_in(n, op.res_buf, image);
             ROMP_REQUIRE(in && out, "conv: bad buffers %d -> %d", op.in_buf, op.out_buf);
             ROMP_REQUIRE(op.res_buf == ROMP_BUF_NONE || res, "conv: bad residual buffer %d", op.res_buf);
-            return launch_conv(op, in, res, out, B, n->mode, st);
+            return launch_conv(op, in, res, out, B, n->mode, variant, n->queues + idx * 8, st);
         }
         case ROMP_OP_FUSESUM: {
             FuseTerm t[4];
@@ -84,15 +92,49 @@ static int run_op(romp_net* n, const romp_op& op, const float* image, int B, flo
             ROMP_REQUIRE(out, "fusesum: bad out buffer %d", op.out_buf);
             return launch_fusesum(t, op.n_terms, out, B, op.H, op.W, op.Cout, op.out_cstride, op.out_coff, op.relu, st);
         }
+        case ROMP_OP_FORK:
+        case ROMP_OP_JOIN:
+            return ROMP_OK;              // stream markers: handled by run_all
         default:
             set_error("unknown op kind %d", op.kind);
             return ROMP_EINVAL;
     }
 }
 
+static const std::vector<int>* tuned_for(romp_net* n, int B) {
+    auto it = n->tuned.find(B);
+    return it == n->tuned.end() ? nullptr : &it->second;
+}
+
+static int reset_queues(romp_net* n, hipStream_t st) {
+    ROMP_HIP_CHECK(hipMemsetAsync(n->queues, 0, n->ops.size() * 8 * sizeof(int), st));
+    return ROMP_OK;
+}
+
 static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st) {
+    int rc = reset_queues(n, st);
+    if (rc) return rc;
+    const std::vector<int>* tv = tuned_for(n, B);
+    const bool ms = n->use_streams && n->mode == 0;
     for (size_t i = 0; i < n->ops.size(); ++i) {
-        int rc = run_op(n, n->ops[i], image, B, center, params, st);
+        const romp_op& op = n->ops[i];
+        if (op.kind == ROMP_OP_FORK) {
+            if (!ms) continue;
+            ROMP_REQUIRE(op.Cin >= 1 && op.Cin <= 3, "fork: %d side streams", op.Cin);
+            ROMP_HIP_CHECK(hipEventRecord(n->ev_fork, st));
+            for (int k = 0; k < op.Cin; ++k) ROMP_HIP_CHECK(hipStreamWaitEvent(n->side[k], n->ev_fork, 0));
+            continue;
+        }
+        if (op.kind == ROMP_OP_JOIN) {
+            if (!ms) continue;
+            for (int k = 0; k < op.Cin; ++k) {
+                ROMP_HIP_CHECK(hipEventRecord(n->ev_join[k], n->side[k]));
+                ROMP_HIP_CHECK(hipStreamWaitEvent(st, n->ev_join[k], 0));
+            }
+            continue;
+        }
+        hipStream_t s = (ms && op.stream >= 1 && op.stream <= 3) ? n->side[op.stream - 1] : st;
+        rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, s);
         if (rc) return rc;
     }
     return ROMP_OK;
@@ -123,6 +165,20 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
         e = hipMemset(n->bufs[i], 0, bytes);
         if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); romp_net_destroy(n); return ROMP_EHIP; }
     }
+    if (hipMalloc((void**)&n->queues, (size_t)n_ops * 8 * sizeof(int)) != hipSuccess) {
+        set_error("queue allocation failed");
+        romp_net_destroy(n);
+        return ROMP_ENOMEM;
+    }
+    bool ok = hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 3 && ok; ++k)
+        ok = hipStreamCreateWithFlags(&n->side[k], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&n->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        set_error("side stream / event creation failed");
+        romp_net_destroy(n);
+        return ROMP_EHIP;
+    }
     *out = n;
     return ROMP_OK;
 }
@@ -130,6 +186,14 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
 int romp_net_set_mode(romp_net* n, int mode) {
     ROMP_REQUIRE(n && (mode == 0 || mode == 1), "romp_net_set_mode: bad arguments");
     n->mode = mode;
+    return ROMP_OK;
+}
+
+int romp_net_set_streams(romp_net* n, int enable) {
+    ROMP_REQUIRE(n, "romp_net_set_streams: null net");
+    n->use_streams = enable ? 1 : 0;
+    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
+    n->graphs.clear();
     return ROMP_OK;
 }
 
@@ -163,6 +227,52 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     return ROMP_OK;
 }
 
+// Measure every valid kernel variant of every conv op at batch B (on the arena's own buffers: the
+// data is whatever the last forward left there, timing does not depend on it) and keep the fastest.
+int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
+    ROMP_REQUIRE(n && B > 0 && iters > 0, "romp_net_autotune: bad arguments");
+    if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int> best(n->ops.size(), -1);
+    hipEvent_t e0, e1;
+    ROMP_HIP_CHECK(hipEventCreate(&e0));
+    ROMP_HIP_CHECK(hipEventCreate(&e1));
+    // scratch targets for ops that read the caller's image / write the caller's output tensors
+    float* scratch = nullptr;
+    ROMP_HIP_CHECK(hipMalloc((void**)&scratch, (size_t)B * 64 * 64 * 145 * sizeof(float)));
+    int rc = ROMP_OK;
+    for (size_t i = 0; i < n->ops.size() && rc == ROMP_OK; ++i) {
+        const romp_op& op = n->ops[i];
+        if (op.kind != ROMP_OP_CONV) continue;
+        float best_ms = 1e30f;
+        for (int v = 0; v < conv_num_variants(); ++v) {
+            if (!conv_variant_valid(op, v)) continue;
+            float ms_min = 1e30f;
+            for (int it = 0; it < iters + 1 && rc == ROMP_OK; ++it) {
+                rc = reset_queues(n, st);
+                if (rc) break;
+                hipEventRecord(e0, st);
+                rc = run_op(n, i, v, scratch, B, scratch, scratch, st);
+                hipEventRecord(e1, st);
+                if (hipEventSynchronize(e1) != hipSuccess) { set_error("autotune: kernel failed (op %zu variant %d)", i, v); rc = ROMP_EHIP; break; }
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (it > 0 && ms < ms_min) ms_min = ms;      // first run is a warm-up
+            }
+            if (ms_min < best_ms) { best_ms = ms_min; best[i] = v; }
+        }
+    }
+    hipFree(scratch);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (rc == ROMP_OK) {
+        n->tuned[B] = best;
+        for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);     // captured with the old choices
+        n->graphs.clear();
+    }
+    return rc;
+}
+
 int romp_net_profile(romp_net* n, const float* image, int B, float* center, float* params, void* stream,
                      float* ms_out, int iters) {
     ROMP_REQUIRE(n && image && center && params && ms_out && B > 0 && iters > 0, "romp_net_profile: bad arguments");
@@ -172,11 +282,14 @@ int romp_net_profile(romp_net* n, const float* image, int B, float* center, floa
     std::vector<hipEvent_t> ev(nops + 1);
     for (auto& e : ev) ROMP_HIP_CHECK(hipEventCreate(&e));
     for (size_t i = 0; i < nops; ++i) ms_out[i] = 0.f;
+    const std::vector<int>* tv = tuned_for(n, B);
     int rc = ROMP_OK;
     for (int it = 0; it < iters && rc == ROMP_OK; ++it) {
+        rc = reset_queues(n, st);
+        if (rc) break;
         hipEventRecord(ev[0], st);
         for (size_t i = 0; i < nops; ++i) {
-            rc = run_op(n, n->ops[i], image, B, center, params, st);
+            rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, st);
             if (rc) break;
             hipEventRecord(ev[i + 1], st);
         }
@@ -213,21 +326,40 @@ void romp_net_destroy(romp_net* n) {
     for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
     for (float* p : n->bufs)
         if (p) hipFree(p);
+    if (n->queues) hipFree(n->queues);
+    for (int k = 0; k < 3; ++k) {
+        if (n->side[k]) hipStreamDestroy(n->side[k]);
+        if (n->ev_join[k]) hipEventDestroy(n->ev_join[k]);
+    }
+    if (n->ev_fork) hipEventDestroy(n->ev_fork);
     delete n;
 }
 
-int romp_conv_forward(const romp_op* op, const float* in, const float* res, float* out, int B, int mode, void* stream) {
+int romp_conv_forward(const romp_op* op, const float* in, const float* res, float* out, int B, int mode, int variant,
+                      void* stream) {
     ROMP_REQUIRE(op && in && out && B > 0, "romp_conv_forward: bad arguments");
     if (op->kind == ROMP_OP_STEM) return launch_stem(*op, in, out, B, (hipStream_t)stream);
     ROMP_REQUIRE(op->kind == ROMP_OP_CONV, "romp_conv_forward: op kind %d", op->kind);
-    return launch_conv(*op, in, res, out, B, mode, (hipStream_t)stream);
+    return launch_conv(*op, in, res, out, B, mode, variant, nullptr, (hipStream_t)stream);
 }
 
-int romp_conv_describe(const romp_op* op, int B, char* out, int n) {
+int romp_conv_num_variants(void) { return conv_num_variants(); }
+
+int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) {
     ROMP_REQUIRE(op && out && n > 0 && B > 0, "romp_conv_describe: bad arguments");
     if (op->kind == ROMP_OP_STEM) { snprintf(out, n, "stem_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FUSESUM) { snprintf(out, n, "fusesum"); return ROMP_OK; }
-    return describe_conv(*op, B, out, n);
+    if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
+    ROMP_REQUIRE(op->kind == ROMP_OP_CONV, "romp_conv_describe: op kind %d", op->kind);
+    if (variant >= 0 && !conv_variant_valid(*op, variant)) { set_error("variant %d not valid for this op", variant); return ROMP_EINVAL; }
+    return describe_conv(*op, B, variant, out, n);
+}
+
+int romp_net_tuned_variant(romp_net* n, int B, int op_index) {
+    if (!n || op_index < 0 || op_index >= (int)n->ops.size()) return -1;
+    const std::vector<int>* tv = tuned_for(n, B);
+    return tv ? (*tv)[op_index] : -1;
 }
 
 }  // extern "C"

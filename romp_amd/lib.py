@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libromp_hip.so')
 
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
-OP_STEM, OP_CONV, OP_FUSESUM = 1, 2, 3
+OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN = 1, 2, 3, 4, 5
 
 
 class RompOp(C.Structure):
@@ -29,6 +29,7 @@ class RompOp(C.Structure):
         ('cin_pad', C.c_int32), ('cout_pad', C.c_int32),
         ('n_terms', C.c_int32),
         ('term_buf', C.c_int32 * 4), ('term_shift', C.c_int32 * 4), ('term_cstride', C.c_int32 * 4),
+        ('stream', C.c_int32), ('reserved', C.c_int32),
         ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
     ]
 
@@ -61,10 +62,14 @@ def load():
         'romp_net_write_buffer': (C.c_int, [vp, i32, vp, C.c_int64, vp]),
         'romp_net_set_mode': (C.c_int, [vp, i32]),
         'romp_net_set_graph': (C.c_int, [vp, i32]),
+        'romp_net_set_streams': (C.c_int, [vp, i32]),
         'romp_net_profile': (C.c_int, [vp, vp, i32, vp, vp, vp, C.POINTER(C.c_float), i32]),
         'romp_net_destroy': (None, [vp]),
-        'romp_conv_forward': (C.c_int, [C.POINTER(RompOp), vp, vp, vp, i32, i32, vp]),
-        'romp_conv_describe': (C.c_int, [C.POINTER(RompOp), i32, C.c_char_p, i32]),
+        'romp_conv_forward': (C.c_int, [C.POINTER(RompOp), vp, vp, vp, i32, i32, i32, vp]),
+        'romp_conv_num_variants': (C.c_int, []),
+        'romp_conv_describe': (C.c_int, [C.POINTER(RompOp), i32, i32, C.c_char_p, i32]),
+        'romp_net_autotune': (C.c_int, [vp, i32, i32, vp]),
+        'romp_net_tuned_variant': (C.c_int, [vp, i32, i32]),
         'romp_parse': (C.c_int, [vp, vp, i32, f, i32, C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'romp_rot6d_to_aa': (C.c_int, [vp, i32, vp, vp]),
         'smpl_ctx_create': (C.c_int, [C.POINTER(vp), vp, vp, i32, vp, vp, vp, i64p, vp, vp, i64p, i32, vp]),
@@ -83,8 +88,9 @@ def load():
 
 
 EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_forward', 'romp_net_read_buffer',
-           'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_profile', 'romp_net_destroy',
-           'romp_conv_forward', 'romp_conv_describe', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
+           'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_set_streams', 'romp_net_profile', 'romp_net_destroy',
+           'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_describe',
+           'romp_net_autotune', 'romp_net_tuned_variant', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
            'romp_project']
 
 

@@ -42,6 +42,10 @@ class RompNet:
         """0 = MFMA kernels (default), 1 = naive direct-conv cross-check kernels."""
         L.check(self.lib.romp_net_set_mode(self._h, int(mode)))
 
+    def set_streams(self, enable):
+        """Run independent HRNet branches on side HIP streams (default on)."""
+        L.check(self.lib.romp_net_set_streams(self._h, int(bool(enable))))
+
     def set_graph(self, enable):
         L.check(self.lib.romp_net_set_graph(self._h, int(bool(enable))))
 
@@ -64,6 +68,21 @@ class RompNet:
         """Reference layout: center_maps (B,1,64,64), params_maps (B,145,64,64) (views, no copy)."""
         c, p = self.forward_nhwc(image)
         return c.unsqueeze(1), p.permute(0, 3, 1, 2)
+
+    def autotune(self, B, iters=2):
+        """Pick the fastest conv kernel variant per layer for batch size B (measured on device)."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.romp_net_autotune(self._h, int(B), int(iters), L.stream_ptr(self.device)))
+
+    def variant_names(self, B):
+        """Kernel variant name per op (tuned choice if autotune(B) ran, else the heuristic)."""
+        buf = C.create_string_buffer(128)
+        names = []
+        for i, op in enumerate(self.program.ops):
+            v = self.lib.romp_net_tuned_variant(self._h, int(B), i)
+            L.check(self.lib.romp_conv_describe(C.byref(op), int(B), v, buf, 128))
+            names.append(buf.value.decode())
+        return names
 
     def read_buffer(self, buf, B):
         n = self.program.buf_floats[buf] * B

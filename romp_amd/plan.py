@@ -18,7 +18,8 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_CONV, OP_FUSESUM, OP_STEM, RompOp
+from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_CONV, OP_FORK, OP_FUSESUM, OP_JOIN, OP_STEM,
+                  RompOp)
 
 BN_EPS = 1e-5
 HEAD_IN_CH = 40          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 8
@@ -85,14 +86,23 @@ class Program:
         self.consts: List[torch.Tensor] = []
         self.buf_floats: List[int] = []
         self._free: Dict[int, List[int]] = {}
+        self._pfree: Dict[int, Dict[int, List[int]]] = {}     # per-stream free lists inside a fork/join region
+        self.cur_stream = 0
+        self.in_parallel = False
+        self.parallel = True                                   # emit FORK/JOIN (False: one stream)
         self.persistent = set()
         self.head_in_buf: Optional[int] = None
 
     # ---- buffers -------------------------------------------------------------------------
     def alloc(self, floats, persistent=False):
-        lst = self._free.get(floats)
-        if lst and not persistent:
-            return lst.pop()
+        if not persistent:
+            if self.in_parallel:                                # buffers this stream released itself
+                lst = self._pfree.get(self.cur_stream, {}).get(floats)
+                if lst:
+                    return lst.pop()
+            lst = self._free.get(floats)                        # released before the fork: nobody uses them
+            if lst:
+                return lst.pop()
         self.buf_floats.append(int(floats))
         b = len(self.buf_floats) - 1
         if persistent:
@@ -100,10 +110,41 @@ class Program:
         return b
 
     def free(self, act: Act):
+        """Return a buffer for reuse.  Inside a fork/join region it only becomes visible to the
+        stream that released it (other streams run concurrently); join() publishes it to all."""
         if act.buf >= 0 and act.buf not in self.persistent:
-            lst = self._free.setdefault(self.buf_floats[act.buf], [])
+            pool = self._pfree.setdefault(self.cur_stream, {}) if self.in_parallel else self._free
+            lst = pool.setdefault(self.buf_floats[act.buf], [])
             assert act.buf not in lst, 'double free of buffer %d' % act.buf
             lst.append(act.buf)
+
+    def _marker(self, kind, n):
+        op = RompOp()
+        op.kind, op.Cin = kind, n
+        op.in_buf = op.out_buf = op.res_buf = BUF_NONE
+        self.ops.append(op)
+        self.names.append('fork' if kind == OP_FORK else 'join')
+        self.flops.append(0.0)
+        self.bytes.append(0.0)
+
+    def fork(self, n_side):
+        """Side streams 1..n_side may run concurrently with the main stream until join()."""
+        assert not self.in_parallel
+        if self.parallel and n_side > 0:
+            self._marker(OP_FORK, n_side)
+            self.in_parallel, self._n_side = True, n_side
+
+    def on(self, stream):
+        self.cur_stream = stream if self.in_parallel else 0
+
+    def join(self):
+        if self.in_parallel:
+            self._marker(OP_JOIN, self._n_side)
+            for pool in self._pfree.values():
+                for size, lst in pool.items():
+                    self._free.setdefault(size, []).extend(lst)
+            self._pfree = {}
+            self.in_parallel, self.cur_stream = False, 0
 
     def new_act(self, C_, H, W):
         return Act(self.alloc(C_ * H * W), C_, H, W, C_)
@@ -145,6 +186,7 @@ class Program:
             op.res_cstride, op.res_coff, op.res_gstride = res.cstride, res.coff, (cout if groups > 1 else 0)
         op.cin_pad, op.cout_pad = cin_pad, cout_pad
         op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+        op.stream = self.cur_stream
         self.ops.append(op)
         self.names.append(name)
         self.flops.append(2.0 * Ho * Wo * cout * cin * ksize * ksize * groups)
@@ -182,6 +224,7 @@ class Program:
             assert t.C == t0.C and t.coff == 0 and (t.H << s) == H
             op.term_buf[k], op.term_shift[k], op.term_cstride[k] = t.buf, s, t.cstride
             nbytes += 4.0 * t.H * t.W * t.C
+        op.stream = self.cur_stream
         self.ops.append(op)
         self.names.append(name)
         self.flops.append(float(H * W * t0.C * (len(terms) - 1)))
@@ -233,10 +276,15 @@ def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> P
     P.free(x)
 
     def hr_module(prefix, xs, n_out, final_out: Optional[Act] = None):
-        """HighResolutionModule.forward (model.py:226-244)."""
+        """HighResolutionModule.forward (model.py:226-244).  The branches are independent until the
+        fuse (model.py:230-231) and so are the fuse outputs: each runs on its own HIP stream, so the
+        persistent conv kernels of different branches share the CUs and fill each other's barrier /
+        load gaps and launch tails."""
         nb = len(xs)
         xs = list(xs)
+        P.fork(nb - 1)
         for br in range(nb):                                     # branches: 4 BasicBlocks each
+            P.on(br)
             for k in range(4):
                 q = f'{prefix}branches.{br}.{k}.'
                 t = cbr(q + 'conv1', xs[br], q + 'conv1', q + 'bn1', 3, 1, True)
@@ -244,16 +292,21 @@ def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> P
                 P.free(t)
                 P.free(xs[br])
                 xs[br] = y
-        outs = []
+        P.join()
+        outs, all_temps = [], []
+        by_output = n_out > 1
+        P.fork((n_out if by_output else nb) - 1)
+        pending = []
         for i in range(n_out):
-            terms, shifts, temps = [], [], []
+            terms, shifts = [], []
             for j in range(nb):
+                P.on(i if by_output else j)
                 q = f'{prefix}fuse_layers.{i}.{j}.'
                 if j == i:
                     terms.append(xs[j]); shifts.append(0)
                 elif j > i:                                      # 1x1 conv + BN, upsample folded into fusesum
                     t = cbr(q + 'up', xs[j], q + '0', q + '1', 1, 1, False)
-                    terms.append(t); shifts.append(j - i); temps.append(t)
+                    terms.append(t); shifts.append(j - i); all_temps.append(t)
                 else:                                            # chain of stride-2 3x3 convs
                     t = xs[j]
                     for k in range(i - j):
@@ -261,11 +314,17 @@ def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> P
                         if t is not xs[j]:
                             P.free(t)
                         t = t2
-                    terms.append(t); shifts.append(0); temps.append(t)
-            outs.append(P.fusesum(f'{prefix}fuse.{i}', terms, shifts, True,
-                                  out=final_out if (final_out is not None and i == 0) else None))
-            for t in temps:
-                P.free(t)
+                    terms.append(t); shifts.append(0); all_temps.append(t)
+            if by_output:                                        # the sum follows its terms on the same stream
+                P.on(i)
+                outs.append(P.fusesum(f'{prefix}fuse.{i}', terms, shifts, True))
+            else:
+                pending.append((terms, shifts))
+        P.join()
+        for terms, shifts in pending:                            # single output: terms ran in parallel, sum after the join
+            outs.append(P.fusesum(f'{prefix}fuse.0', terms, shifts, True, out=final_out))
+        for t in all_temps:
+            P.free(t)
         for xj in xs:
             P.free(xj)
         return outs

@@ -111,10 +111,19 @@ def test_program_matches_reference_inventory(program):
 def test_program_buffer_liveness(program):
     """No op may read a buffer whose producer has since been overwritten: replay the program
     symbolically, tagging each buffer with the op that last wrote it."""
-    from romp_amd.lib import OP_CONV, OP_FUSESUM, OP_STEM
+    from romp_amd.lib import OP_CONV, OP_FORK, OP_FUSESUM, OP_JOIN, OP_STEM
     writer = {}
-    expected = {}          # (consumer op index, buffer) -> producer recorded at plan time is implicit:
+    region = None          # inside FORK..JOIN: buffer -> set of streams that touched it, and how
     for i, op in enumerate(program.ops):
+        if op.kind == OP_FORK:
+            assert region is None and 1 <= op.Cin <= 3
+            region = {'n': op.Cin, 'w': {}, 'r': {}}
+            continue
+        if op.kind == OP_JOIN:
+            assert region is not None and op.Cin == region['n']
+            region = None
+            continue
+        assert (op.stream == 0) if region is None else (0 <= op.stream <= region['n'])
         reads = []
         if op.kind in (OP_CONV, OP_STEM) and op.in_buf >= 0:
             reads.append(op.in_buf)
@@ -125,8 +134,20 @@ def test_program_buffer_liveness(program):
         for b in reads:
             assert b in writer, 'op %d (%s) reads buffer %d before it was written' % (i, program.names[i], b)
             assert b != op.out_buf or b == program.head_in_buf, 'op %d runs in place on buffer %d' % (i, b)
+            if region is not None:
+                # concurrent streams: nobody else may have written this buffer inside the region
+                assert region['w'].get(b, {op.stream}) == {op.stream}, \
+                    'op %d (%s) on stream %d reads buffer %d written by another stream of the region' % (
+                        i, program.names[i], op.stream, b)
+                region['r'].setdefault(b, set()).add(op.stream)
         if op.out_buf >= 0:
+            if region is not None:
+                others = (region['r'].get(op.out_buf, set()) | region['w'].get(op.out_buf, set())) - {op.stream}
+                assert not others, 'op %d (%s) on stream %d writes buffer %d used by stream(s) %s in the region' % (
+                    i, program.names[i], op.stream, op.out_buf, others)
+                region['w'].setdefault(op.out_buf, set()).add(op.stream)
             writer[op.out_buf] = i
+    assert region is None
     assert program.head_in_buf in writer
     # arena stays small because of reuse: < 100 MB per image although 323 ops produce ~560 MB of activations
     assert sum(program.buf_floats) * 4 / 1e6 < 100
@@ -138,7 +159,7 @@ def test_conv_describe_every_op(program):
     buf = C.create_string_buffer(128)
     for B in (1, 32):
         for op in program.ops:
-            L.check(h.romp_conv_describe(C.byref(op), B, buf, 128))
+            L.check(h.romp_conv_describe(C.byref(op), B, -1, buf, 128))
             assert buf.value
 
 

@@ -200,13 +200,22 @@ def test_conv_layer(dev, case, B):
     op = P.ops[0]
     xd, rd = x.to(dev), (res.to(dev) if res is not None else None)
     lib = L.load()
-    for mode in (0, 1):
+    buf = C.create_string_buffer(128)
+    # naive cross-check kernel, the heuristic variant, then EVERY variant able to run this layer
+    runs = [(1, -1), (0, -1)] + [(0, v) for v in range(lib.romp_conv_num_variants())
+                                 if lib.romp_conv_describe(C.byref(op), B, v, buf, 128) == 0]
+    assert len(runs) >= 3
+    for mode, variant in runs:
         out = torch.full((B, Ho, Ho, cout), float('nan'), device=dev)
-        L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), L.ptr(rd), L.ptr(out), B, mode, L.stream_ptr(dev)))
+        L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), L.ptr(rd), L.ptr(out), B, mode, variant, L.stream_ptr(dev)))
         torch.cuda.synchronize()
         err = (out.cpu() - ref).abs().max().item()
-        print(f'mode {mode}: max-abs err {err:.3e} (ref absmax {ref.abs().max():.2f})')
-        assert err < 2e-5, f'mode {mode} err {err}'
+        name = 'naive'
+        if mode == 0:
+            L.check(lib.romp_conv_describe(C.byref(op), B, variant, buf, 128))
+            name = buf.value.decode()
+        print(f'{name} (variant {variant}): max-abs err {err:.3e} (ref absmax {ref.abs().max():.2f})')
+        assert err < 3e-5, f'{name} err {err}'
 
 
 # ------------------------------------------------------------------------------ network
@@ -244,6 +253,16 @@ def test_net_vs_oracle_batch(dev, net0):
     # batch position independence: image 2 alone == image 2 in the batch
     cm1, pm1 = net0(img[2:3].to(dev))
     assert (cm1 - cm[2:3]).abs().max().item() < 2e-5 and (pm1 - pm[2:3]).abs().max().item() < 2e-5
+    # branch-parallel side streams vs one stream: same kernels, same arithmetic -> identical maps
+    net0.set_streams(False)
+    cm_s, pm_s = net0(img.to(dev))
+    net0.set_streams(True)
+    assert torch.equal(cm_s, cm) and torch.equal(pm_s, pm)
+    # autotuned kernel variants keep parity
+    net0.autotune(3, iters=1)
+    cm_t, pm_t = net0(img.to(dev))
+    assert (cm_t.cpu() - cm_o).abs().max().item() < 1e-4 and (pm_t.cpu() - pm_o).abs().max().item() < 1e-4
+    cm, pm = cm_t, pm_t
     # hipGraph replay gives the same maps as eager launches
     net0.set_graph(True)
     s = torch.cuda.Stream()
