@@ -171,3 +171,76 @@ if __name__ == '__main__':
     golden_projection(ref)
     golden_net(ref)
     print('golden fixtures written to', GOLD)
+
+
+# ------------------------------------------------------------------------------------------- BEV
+def _load_reference_bev():
+    pkg = types.ModuleType('bev')
+    pkg.__path__ = [os.path.join(REF, 'bev')]
+    sys.modules['bev'] = pkg
+    mods = {}
+    for name in ('post_parser', 'model'):
+        spec = importlib.util.spec_from_file_location(f'bev.{name}', os.path.join(REF, 'bev', f'{name}.py'))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[f'bev.{name}'] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+def golden_bev():
+    """Reference BEVv1 (bev/model.py:104-250) on the oracle's synthetic BEV weights."""
+    from oracle import bev_oracle as BO
+    bev = _load_reference_bev()
+    sd = BO.make_bev_state_dict(0)
+    img = O.make_images(1, seed=4)
+    net = bev['model'].BEVv1(center_thresh=0.1).eval()
+    ref_keys = [k for k in net.state_dict() if not k.endswith('num_batches_tracked')]
+    assert sorted(ref_keys) == sorted(sd.keys()), set(ref_keys) ^ set(sd.keys())
+    for k in ref_keys:
+        assert tuple(net.state_dict()[k].shape) == tuple(sd[k].shape), k
+    net.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        x = net.backbone(img)
+        c3d, cam3d, c_fv = net.coarse2fine_localization(x)
+    # threshold with ~12 detections on this input
+    mx = torch.nn.functional.max_pool3d(c3d.unsqueeze(1), 5, 1, 2).squeeze(1)
+    peaks = torch.sort(c3d[(mx == c3d)].flatten(), descending=True)[0]
+    gaps = (peaks[7:24] - peaks[8:25]).numpy()                  # cut at the widest gap among the top peaks
+    n_det = 8 + int(np.argmax(gaps))
+    thresh = float((peaks[n_det - 1] + peaks[n_det]) / 2)
+    assert thresh > 0 and gaps.max() > 1e-4
+    net.centermap_parser.conf_thresh = thresh
+    with torch.no_grad():
+        out = net(img)
+    pk = bev['post_parser'].pack_params_dict(out['params_pred'])
+    trans = bev['post_parser'].denormalize_cam_params_to_trans(pk['cam'])
+    rs = np.random.RandomState(3)
+    pos = np.sort(rs.choice(64 * 128 * 128, 4096, replace=False))
+    np.savez_compressed(
+        os.path.join(GOLD, 'bev_b1.npz'), thresh=np.float32(thresh), sample_pos=pos,
+        center3d_samples=c3d[0].reshape(-1).numpy()[pos], cam3d_samples=cam3d[0].reshape(3, -1).numpy()[:, pos],
+        center3d_sum=np.float64(c3d.double().sum()), cam3d_sum=cam3d[0].reshape(3, -1).double().sum(1).numpy(),
+        center_fv=c_fv[0, 0].numpy(),
+        pred_batch_ids=out['pred_batch_ids'].numpy(), pred_czyxs=out['pred_czyxs'].numpy(),
+        center_confs=out['center_confs'].numpy(), params_pred=out['params_pred'].numpy(), cam_czyx=out['cam_czyx'].numpy(),
+        cam=pk['cam'].numpy(), smpl_thetas=pk['smpl_thetas'].numpy(), smpl_betas=pk['smpl_betas'].numpy(), cam_trans=trans.numpy())
+    print('bev: thresh %.4f detections %d' % (thresh, len(out['pred_batch_ids'])))
+    # SMPLA_parser with one "baby" (betas[:,10] > 0.8): bev/post_parser.py:255-278
+    smpla = O.make_synthetic_smpl(seed=0, n_betas=11)
+    smil = O.make_synthetic_smpl(seed=5, n_betas=10)
+    with tempfile.TemporaryDirectory() as td:
+        pa, pi = os.path.join(td, 'a.pth'), os.path.join(td, 'i.pth')
+        torch.save(smpla, pa); torch.save(smil, pi)
+        parser = bev['post_parser'].SMPLA_parser(pa, pi)
+    g = torch.Generator().manual_seed(6)
+    betas = torch.randn(5, 11, generator=g) * 0.5
+    betas[:, 10] = torch.tensor([0.1, 0.95, 0.3, 0.85, -0.2])
+    thetas = 0.3 * torch.randn(5, 72, generator=g)
+    v, j, _ = parser(betas, thetas)
+    np.savez_compressed(os.path.join(GOLD, 'smpla_parser_n5.npz'), betas=betas.numpy(), thetas=thetas.numpy(),
+                        verts=v.numpy(), joints=j.numpy())
+
+
+if __name__ == '__main__' and os.environ.get('GOLDEN_ONLY', '') in ('', 'bev'):
+    golden_bev()
