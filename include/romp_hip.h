@@ -58,6 +58,13 @@ const char* romp_last_error(void);
 #define ROMP_OP_FUSESUM   3     /* y = relu(sum_t up_nearest(T_t))   (model.py:233-244)           */
 #define ROMP_OP_FORK      4     /* side streams 1..Cin start after everything enqueued so far     */
 #define ROMP_OP_JOIN      5     /* the main stream waits for side streams 1..Cin                  */
+/* BEV head (bev/model.py:188-215).  For these three kinds `weight/scale/shift` are HOST pointers
+ * (small constant tables passed to the kernels by value). */
+#define ROMP_OP_BEV_PACK  6     /* in_buf maps_fv (B,128,128,4) + res_buf feats (..,16) -> out_buf (B,128,2560)   */
+#define ROMP_OP_BEV_MAPS  7     /* in_buf maps_fv, res_buf bv (B,128,128) -> out_buf center3d, term_buf[0] cam3d;
+                                   weight = 64 scale anchors (get_cam3dmap_anchor, bev/model.py:77-87)          */
+#define ROMP_OP_CONV3D    8     /* 3x3x3 conv Cin->Cin (1|3) on (B,C,64,128,128) + scale/shift (+res) (+ReLU)     */
+/* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 typedef struct romp_op {
     int32_t kind;
@@ -137,6 +144,28 @@ int  romp_parse(const float* center_maps, const float* params_maps_nhwc, int B,
                 int32_t* workspace /* B*(2*max_person+2) int32 */, void* stream);
 /* rot6D_to_angular (utils.py:471-475): x6 (n,6) -> aa (n,3) */
 int  romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream);
+
+/* ------------------------------------------------------------------ seam #2b: BEV 3-D parsing */
+
+/* CenterMap3D.parse_3dcentermap (bev/post_parser.py:44-66): MaxPool3d(5) NMS + top-K over
+ * center_maps_3d (B,64,128,128).  conf_thresh must be > 0.  Rows batch-major, score-descending,
+ * ties by lower flat zyx index.  workspace: romp_bev_workspace_ints(B, max_person) int32.
+ * Synchronises the stream once (count). */
+int  romp_bev_workspace_ints(int B, int max_person);
+int  romp_bev_parse(const float* center_maps_3d, int B, float conf_thresh, int max_person, int32_t* count_host,
+                    int32_t* batch_ids, int32_t* czyx /* (N,3) */, float* confs, int32_t* workspace, void* stream);
+/* cam gather (bev/model.py:242) + mesh_parameter_regression (:225-230) + pack_params_dict
+ * (bev/post_parser.py:240-253) + denormalize_cam_params_to_trans (:114-128) for N detections.
+ * cam_maps_3d (B,3,64,128,128); fv_features (B,128,128,feat_cstride>=128) NHWC; MLP weights are
+ * TRANSPOSED ([in][out]): w1t (128,512), w2t (512,512), w3t (512,143); emb (128,128).
+ * -> params_pred (N,146), cam_czyx int32 (N,3), cam (N,3), thetas (N,72), betas (N,11), cam_trans (N,3) */
+int  romp_bev_regress(const float* cam_maps_3d, const float* fv_features, int feat_cstride, int N,
+                      const int32_t* batch_ids, const int32_t* czyx, const float* anchors_host, const float* emb,
+                      const float* w1t, const float* b1, const float* w2t, const float* b2, const float* w3t,
+                      const float* b3, float* params_pred, int32_t* cam_czyx, float* cam, float* thetas, float* betas,
+                      float* cam_trans, void* stream);
+/* Device address of arena buffer `buf` (e.g. the BEV front-view feature map). */
+float* romp_net_buffer_ptr(romp_net* net, int buf);
 
 /* ------------------------------------------------------------------ seam #3: SMPL */
 

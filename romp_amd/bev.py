@@ -1,0 +1,199 @@
+"""BEV on the MI355X -- mirror of ``simple_romp/bev/main.py`` (``bev_settings`` :27-87, ``BEV`` :91-181)
+and of the device-side steps of ``BEVv1.forward`` (bev/model.py:232-250) for BASELINE config 4.
+
+    from romp_amd import bev
+    model = bev.BEV(bev.bev_settings([]), state_dict=..., smpla_model=..., smil_model=...)
+    outputs = model(bgr_image)         # dict of numpy arrays, or None
+
+Network (HRNet-32 + BEV head), 3-D center parsing, per-person regression, SMPL-A / SMIL meshes all
+run in libromp_hip.so.  Not built yet (SURVEY.md §8f-2 "next"): perspective projection of the joints,
+projection-based duplicate suppression and outlier removal (bev/post_parser.py:68-107,167-222), and
+the long-image "crowd" sliding window (bev/main.py:184-258, CPU orchestration).
+"""
+import argparse
+import ctypes as C
+import os.path as osp
+import sys
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import lib as L
+from .bev_plan import DEPTH, MAP, build_bev_hrnet32, cam3dmap_anchor
+from .net import RompNet
+from .smpl import SMPL
+from .utils import convert_tensor2numpy, determine_device, img_preprocess
+
+
+def bev_settings(input_args=sys.argv[1:]):
+    """bev/main.py:27-87 (model_id 2 defaults; rendering / crowd / temporal flags kept for
+    compatibility, the options they enable are outside the MI355X hot path)."""
+    p = argparse.ArgumentParser(description='BEV on MI355X')
+    p.add_argument('-m', '--mode', type=str, default='image')
+    p.add_argument('--model_id', type=int, default=2)
+    p.add_argument('-i', '--input', type=str, default=None)
+    p.add_argument('-o', '--save_path', type=str, default=osp.join(osp.expanduser('~'), 'BEV_results'))
+    p.add_argument('--crowd', action='store_true', help='long-image sliding window (not built)')
+    p.add_argument('--GPU', type=int, default=0)
+    p.add_argument('--overlap_ratio', type=float, default=0.8)
+    p.add_argument('--center_thresh', type=float, default=0.1)
+    p.add_argument('--nms_thresh', type=float, default=20)
+    p.add_argument('--relative_scale_thresh', type=float, default=1.6)
+    p.add_argument('--show_largest', action='store_true')
+    p.add_argument('--calc_smpl', action='store_false')
+    p.add_argument('--render_mesh', action='store_true')
+    p.add_argument('--show', action='store_true')
+    p.add_argument('--smpl_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'SMPLA_NEUTRAL.pth'))
+    p.add_argument('--smil_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'smil_packed_info.pth'))
+    p.add_argument('--model_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'BEV.pth'))
+    p.add_argument('-t', '--temporal_optimize', action='store_true')
+    p.add_argument('--max_batch', type=int, default=32)
+    args = p.parse_args(input_args)
+    if not torch.cuda.is_available():
+        args.GPU = -1
+    return args
+
+
+class CenterMap3D(object):
+    """bev/post_parser.py:19-66 -- parse configuration + the device parse."""
+
+    def __init__(self, conf_thresh):
+        self.size, self.max_person, self.conf_thresh = 128, 64, conf_thresh
+
+    def parse_3dcentermap(self, center_maps):
+        """center_maps (B,64,128,128) device tensor -> [batch_ids (N), center_zyxs (N,3), scores (N)]
+        (int64 / int64 / float32), batch-major and score-descending; empty tensors if nobody."""
+        lib = L.load()
+        dev = center_maps.device
+        if dev.type != 'cuda':
+            raise L.RompHipError('3-D center parsing runs on the HIP device only (no CPU fallback)')
+        cm = center_maps.contiguous().float()
+        B = cm.shape[0]
+        cap = B * self.max_person
+        bids = torch.empty(cap, device=dev, dtype=torch.int32)
+        czyx = torch.empty(cap, 3, device=dev, dtype=torch.int32)
+        conf = torch.empty(cap, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.romp_bev_workspace_ints(B, self.max_person), device=dev, dtype=torch.int32)
+        n = C.c_int32(0)
+        with torch.cuda.device(dev):
+            L.check(lib.romp_bev_parse(L.ptr(cm), B, float(self.conf_thresh), self.max_person, C.byref(n), L.ptr(bids),
+                                       L.ptr(czyx), L.ptr(conf), L.ptr(ws), L.stream_ptr(dev)))
+        N = n.value
+        return [bids[:N].long(), czyx[:N].long(), conf[:N]]
+
+
+class BEVv1(object):
+    """Device-side BEVv1 (bev/model.py:104-250): network program + parse + per-person regression."""
+
+    def __init__(self, state_dict, device, center_thresh=0.1, max_batch=32):
+        self.device = torch.device(device)
+        self.net = RompNet(state_dict, self.device, max_batch=max_batch, builder=build_bev_hrnet32,
+                           out_shapes=((DEPTH, MAP, MAP), (3, DEPTH, MAP, MAP)))
+        self.centermap_parser = CenterMap3D(center_thresh)
+        f = lambda k: state_dict[k].detach().float()
+        dv = lambda t: t.contiguous().to(self.device)
+        self.emb = dv(f('position_embeddings.weight'))
+        self.w1t, self.b1 = dv(f('transformer.0.weight').t()), dv(f('transformer.0.bias'))      # [in][out]
+        self.w2t, self.b2 = dv(f('transformer.3.weight').t()), dv(f('transformer.3.bias'))
+        self.w3t, self.b3 = dv(f('transformer.6.weight').t()), dv(f('transformer.6.bias'))
+        self.anchors = (C.c_float * DEPTH)(*cam3dmap_anchor(60, MAP).tolist())
+
+    def localization(self, images):
+        """coarse2fine_localization: -> center_maps_3d (B,64,128,128), cam_maps_3d (B,3,64,128,128)."""
+        return self.net.forward_nhwc(images)
+
+    @torch.no_grad()
+    def __call__(self, images):
+        """images (B,512,512,3) float on device -> dict like BEVv1.forward (:247-249) or None."""
+        lib = L.load()
+        c3d, cam3d = self.localization(images)
+        bids, czyx, confs = self.centermap_parser.parse_3dcentermap(c3d)
+        N = bids.shape[0]
+        if N == 0:
+            print('No person detected!')
+            return None
+        dev = self.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        out = {'params_pred': torch.empty(N, 146, **f32), 'cam': torch.empty(N, 3, **f32),
+               'smpl_thetas': torch.empty(N, 72, **f32), 'smpl_betas': torch.empty(N, 11, **f32),
+               'cam_trans': torch.empty(N, 3, **f32)}
+        cam_czyx = torch.empty(N, 3, device=dev, dtype=torch.int32)
+        b32, z32 = bids.int().contiguous(), czyx.int().contiguous()
+        P = self.net.program
+        feat_ptr = self.net.buffer_ptr(P.fv_buf) + 4 * P.fv_coff
+        with torch.cuda.device(dev):
+            L.check(lib.romp_bev_regress(L.ptr(cam3d), C.c_void_p(feat_ptr), P.fv_cstride, N, L.ptr(b32), L.ptr(z32),
+                                         self.anchors, L.ptr(self.emb), L.ptr(self.w1t), L.ptr(self.b1), L.ptr(self.w2t),
+                                         L.ptr(self.b2), L.ptr(self.w3t), L.ptr(self.b3), L.ptr(out['params_pred']),
+                                         L.ptr(cam_czyx), L.ptr(out['cam']), L.ptr(out['smpl_thetas']),
+                                         L.ptr(out['smpl_betas']), L.ptr(out['cam_trans']), L.stream_ptr(dev)))
+        out.update({'cam_czyx': cam_czyx.float(), 'center_map_3d': c3d, 'cam_maps_3d': cam3d, 'pred_batch_ids': bids,
+                    'pred_czyxs': czyx, 'center_confs': confs})
+        return out
+
+
+class SMPLA_parser(nn.Module):
+    """bev/post_parser.py:255-278: SMPL-A for adults, SMIL for betas[:,10] > 0.8, always root-aligned."""
+
+    def __init__(self, smpla_path, smil_path):
+        super(SMPLA_parser, self).__init__()
+        self.smil_model = SMPL(smil_path, model_type='smpl')
+        self.smpl_model = SMPL(smpla_path, model_type='smpla')
+        self.baby_thresh = 0.8
+
+    def forward(self, betas=None, thetas=None, root_align=True):
+        baby_mask = betas[:, 10] > self.baby_thresh
+        if baby_mask.sum() > 0:
+            adult_mask = ~baby_mask
+            n = len(thetas)
+            verts = torch.zeros(n, 6890, 3, device=thetas.device)
+            joints = torch.zeros(n, 71, 3, device=thetas.device)
+            verts[baby_mask], joints[baby_mask], face = self.smil_model(betas[baby_mask, :10].contiguous(),
+                                                                        thetas[baby_mask].contiguous(), root_align=root_align)
+            if adult_mask.sum() > 0:
+                verts[adult_mask], joints[adult_mask], face = self.smpl_model(betas[adult_mask].contiguous(),
+                                                                              thetas[adult_mask].contiguous(),
+                                                                              root_align=root_align)
+        else:
+            verts, joints, face = self.smpl_model(betas, thetas, root_align=root_align)
+        return verts, joints, face
+
+
+class BEV(nn.Module):
+    def __init__(self, settings, state_dict=None, smpla_model=None, smil_model=None):
+        super(BEV, self).__init__()
+        self.settings = settings
+        if settings.GPU == -1:
+            raise L.RompHipError('romp_amd.bev needs a HIP device; there is no CPU fallback')
+        if settings.render_mesh or settings.temporal_optimize or settings.crowd:
+            raise NotImplementedError('rendering / temporal smoothing / crowd mode are outside the MI355X hot path')
+        self.tdevice = determine_device(settings.GPU)
+        if state_dict is None:
+            state_dict = torch.load(settings.model_path, map_location='cpu')
+        self.model = BEVv1(state_dict, self.tdevice, center_thresh=settings.center_thresh,
+                           max_batch=getattr(settings, 'max_batch', 32))
+        if settings.calc_smpl:
+            self.smpl_parser = SMPLA_parser(smpla_model if smpla_model is not None else settings.smpl_path,
+                                            smil_model if smil_model is not None else settings.smil_path).to(self.tdevice)
+        self.result_keys = ['smpl_thetas', 'smpl_betas', 'cam', 'cam_trans', 'params_pred', 'center_confs', 'pred_batch_ids']
+
+    @torch.no_grad()
+    def forward_batch(self, images):
+        """[extension] images (B,512,512,3) float on device -> dict of device tensors or None."""
+        out = self.model(images)
+        if out is None:
+            return None
+        res = {k: out[k] for k in self.result_keys}
+        if self.settings.calc_smpl:
+            verts, joints, face = self.smpl_parser(res['smpl_betas'], res['smpl_thetas'])
+            res.update({'verts': verts, 'joints': joints})
+        return res
+
+    def forward(self, image, signal_ID=0, **kwargs):
+        """bev/main.py:139-181 (normal images): BGR uint8 HxWx3 -> dict of numpy arrays or None."""
+        input_image, image_pad_info = img_preprocess(image)
+        res = self.forward_batch(input_image.to(self.tdevice))
+        if res is None:
+            return None
+        return convert_tensor2numpy(res)

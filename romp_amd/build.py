@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libromp_hip.so')
-SOURCES = ['conv_mfma.hip', 'stem_fuse.hip', 'net.hip', 'parse.hip', 'smpl.hip']
+SOURCES = ['conv_mfma.hip', 'stem_fuse.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 
 
@@ -27,7 +27,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'romp_hip.h')]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
+              [os.path.join(HERE, '..', 'include', 'romp_hip.h')]
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     jobs = []

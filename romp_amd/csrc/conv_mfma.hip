@@ -57,12 +57,15 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 struct ConvCfg {
-    static constexpr int TAPS = KS * KS;
-    static constexpr int PAD = KS / 2;
+    // KS = 1: 1x1, 3: 3x3, 13: 1x3 (Conv1d k=3 along W; rows of the "image" are independent sequences)
+    static constexpr int KH = (KS == 13) ? 1 : KS;
+    static constexpr int KW = (KS == 13) ? 3 : KS;
+    static constexpr int TAPS = KH * KW;
+    static constexpr int PADH = KH / 2, PADW = KW / 2;
     static constexpr int RPB = 32 / TW;              // tile rows per 32-pixel block
     static constexpr int TH = 4 * MT * RPB;          // output tile rows
-    static constexpr int HR = (TH - 1) * S + KS;     // haloed input rows
-    static constexpr int HC = (TW - 1) * S + KS;
+    static constexpr int HR = (TH - 1) * S + KH;     // haloed input rows
+    static constexpr int HC = (TW - 1) * S + KW;
     static constexpr int PS = CK + 4;                // LDS floats per pixel (padded)
     static constexpr int NW = NT * 32;               // output channels per work item
     static constexpr int QC = CK / 4;                // float4 per pixel per chunk
@@ -100,11 +103,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
     const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
     const float floor_v = p.relu ? 0.f : -__builtin_inff();
     unsigned pixo[MT];
+    bool rowok[MT];                                  // partial tiles along H (e.g. Conv1d over B < TH sequences)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int mb = wave * MT + m;
         const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
-        pixo[m] = (unsigned)(oy * p.Wo + ox);
+        rowok[m] = oy < p.Ho;
+        pixo[m] = rowok[m] ? (unsigned)(oy * p.Wo + ox) : 0u;
     }
     if (p.vec_io) {
         float4 r[MT][NT][4];
@@ -115,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
-                        r[m][n][g4] = ldg4(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8 + lh * 4)));
+                        r[m][n][g4] = ldg4(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8 + lh * 4)));   // masked rows read pixel 0 (valid memory)
         } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -138,7 +143,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                     v.y = fmaxf(fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y) + r[m][n][g4].y, floor_v);
                     v.z = fmaxf(fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z) + r[m][n][g4].z, floor_v);
                     v.w = fmaxf(fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w) + r[m][n][g4].w, floor_v);
-                    *reinterpret_cast<float4*>(out + (pixo[m] * (unsigned)p.out_cs + (unsigned)(cur.n0 + cl))) = v;
+                    if (rowok[m]) *reinterpret_cast<float4*>(out + (pixo[m] * (unsigned)p.out_cs + (unsigned)(cur.n0 + cl))) = v;
                 }
             }
     } else {
@@ -153,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                     const int co = cur.n0 + cl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if (co + e < p.Cout) {
+                        if (co + e < p.Cout && rowok[m]) {
                             float t = fmaf(acc[m][n][g4 * 4 + e], sSc[cl + e], sSc[C::NW + cl + e]);
                             if (res) t += res[pixo[m] * (unsigned)p.res_cs + (unsigned)(co + e)];
                             out[pixo[m] * (unsigned)p.out_cs + (unsigned)(co + e)] = fmaxf(t, floor_v);
@@ -176,7 +181,7 @@ __device__ __forceinline__ void mma_stage(const float* sA, const float* sB, cons
     float4 xf[2][MT], wf[2][NT];
     auto load = [&](int step, int buf) {
         const int tap = step / (CK / 8), q8 = step % (CK / 8);
-        const int dy = tap / KS, dx = tap % KS;
+        const int dy = tap / C::KW, dx = tap % C::KW;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
             xf[buf][m] = *reinterpret_cast<const float4*>(sA + xoff[m] + (dy * C::HC + dx) * C::PS + q8 * 8);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     auto issue_loads = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
         const float* wg = p.w + (size_t)it.g * p.w_gs;
-        const int iy0 = it.ty * C::TH * S - C::PAD, ix0 = it.tx * TW * S - C::PAD;
+        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
     auto issue_loads = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
         const float* wg = p.w + (size_t)it.g * p.w_gs;
-        const int iy0 = it.ty * C::TH * S - C::PAD, ix0 = it.tx * TW * S - C::PAD;
+        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
@@ -530,10 +535,10 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
         const int b = r / p.Ho;
         const float* in = p.in + (size_t)b * p.H * p.W * p.in_cs + p.in_co + g * p.in_gs;
         const float* wg = p.w + (size_t)g * p.w_gs;
-        const int pad = KS / 2;
+        const int KH = KS == 13 ? 1 : KS, KW = KS == 13 ? 3 : KS;
         float acc = 0.f;
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            const int iy = oy * S - pad + tap / KS, ix = ox * S - pad + tap % KS;
+        for (int tap = 0; tap < KH * KW; ++tap) {
+            const int iy = oy * S - KH / 2 + tap / KW, ix = ox * S - KW / 2 + tap % KW;
             if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
             const float* px = in + ((size_t)iy * p.W + ix) * p.in_cs;
             for (int c = 0; c < p.cin_valid; ++c)
@@ -579,6 +584,9 @@ static ConvVariant kVariants[] = {
     ROMP_CONV_VARIANT(1, 1, 1, 1, 16, 32), ROMP_CONV_VARIANT(1, 1, 1, 2, 16, 32),
     ROMP_CONV_VARIANT(1, 1, 2, 2, 16, 32),
     ROMP_CONV_VARIANT(1, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(1, 1, 2, 2, 32, 16),
+    // 1x3 (Conv1d k=3: BEV bird's-eye-view head, bev/model.py:24-45,179-182)
+    ROMP_CONV_VARIANT(13, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 1, 32, 16),
+    ROMP_CONV_VARIANT(13, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 2, 32, 32),
     // ping-pong (8 waves, two alternating groups)
     ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 16, 16),
     ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 16, 16),
@@ -621,7 +629,7 @@ static int ensure_attrs() {
 static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) {
     if (v.lds > kMaxLds) return false;
     if (v.ks != op.ksize || v.s != op.stride) return false;
-    if (Wo % v.tw || Ho % v.th) return false;
+    if (Wo % v.tw) return false;                     // rows may be partial (masked), columns may not
     if (op.cin_pad % v.ck || op.cout_pad % (v.nt * 32)) return false;
     return true;
 }
@@ -633,9 +641,10 @@ static int choose_variant(const romp_op& op, int Ho, int Wo, int B) {
     for (int i = 0; i < kNumVariants; ++i) {
         const ConvVariant& v = kVariants[i];
         if (!variant_ok(v, op, Ho, Wo)) continue;
-        const long items = (long)B * (Ho / v.th) * (Wo / v.tw) * (op.cout_pad / (v.nt * 32)) * op.groups;
+        const long items = (long)B * ((Ho + v.th - 1) / v.th) * (Wo / v.tw) * (op.cout_pad / (v.nt * 32)) * op.groups;
+        const double eff = (double)Ho / (((Ho + v.th - 1) / v.th) * v.th);   // partial row tiles waste MFMA work
         double fill = items >= 512 ? 1.0 : (double)items / 512.0;
-        double score = fill * (1.0 + 0.25 * (v.mt * v.nt - 1)) * (v.ck >= 16 ? 1.0 : 0.8) * (v.tw == 32 ? 1.05 : 1.0);
+        double score = eff * fill * (1.0 + 0.25 * (v.mt * v.nt - 1)) * (v.ck >= 16 ? 1.0 : 0.8) * (v.tw == 32 ? 1.05 : 1.0);
         if (v.mt * v.nt > 4) score *= 0.5;
         if (score > best_score) { best_score = score; best = i; }
     }
@@ -643,8 +652,9 @@ static int choose_variant(const romp_op& op, int Ho, int Wo, int B) {
 }
 
 static void out_dims(const romp_op& op, int* Ho, int* Wo) {
-    *Ho = (op.H + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
-    *Wo = (op.W + 2 * (op.ksize / 2) - op.ksize) / op.stride + 1;
+    const int kh = op.ksize == 13 ? 1 : op.ksize, kw = op.ksize == 13 ? 3 : op.ksize;
+    *Ho = (op.H + 2 * (kh / 2) - kh) / op.stride + 1;
+    *Wo = (op.W + 2 * (kw / 2) - kw) / op.stride + 1;
 }
 
 int conv_num_variants() { return kNumVariants; }
@@ -657,7 +667,7 @@ bool conv_variant_valid(const romp_op& op, int variant) {
 
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B, int mode,
                 int variant, int* queue, hipStream_t st) {
-    ROMP_REQUIRE(op.ksize == 1 || op.ksize == 3, "conv: ksize %d unsupported", op.ksize);
+    ROMP_REQUIRE(op.ksize == 1 || op.ksize == 3 || op.ksize == 13, "conv: ksize %d unsupported", op.ksize);
     ROMP_REQUIRE(op.stride == 1 || op.stride == 2, "conv: stride %d unsupported", op.stride);
     ROMP_REQUIRE(op.groups >= 1, "conv: groups must be >= 1");
     ROMP_REQUIRE((op.in_cstride & 3) == 0 && (op.in_coff & 3) == 0 && (op.in_gstride & 3) == 0 && (op.Cin & 3) == 0,
@@ -671,7 +681,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.out_cs = op.out_cstride; p.out_co = op.out_coff; p.out_gs = op.out_gstride;
     p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.res_gs = op.res_gstride;
     p.relu = op.relu;
-    p.w_gs = op.ksize * op.ksize * op.cin_pad * op.cout_pad;
+    p.w_gs = (op.ksize == 13 ? 3 : op.ksize * op.ksize) * op.cin_pad * op.cout_pad;
     p.tiles_x = p.tiles_y = p.tiles_total = 1;
     p.nslices = p.ns_total = p.n_queues = p.per_queue = 1;
     p.queue = nullptr;
@@ -694,7 +704,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
                  op.ksize, op.stride, op.Cin, op.cin_pad, op.Cout, op.cout_pad, p.Ho, p.Wo);
     const ConvVariant& v = kVariants[variant];
     p.tiles_x = p.Wo / v.tw;
-    p.tiles_y = p.Ho / v.th;
+    p.tiles_y = (p.Ho + v.th - 1) / v.th;
     p.tiles_total = B * p.tiles_x * p.tiles_y;
     p.nslices = op.cout_pad / (v.nt * 32);
     p.ns_total = p.nslices * op.groups;

@@ -71,7 +71,38 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(in && out, "stem: bad buffers %d -> %d", op.in_buf, op.out_buf);
             return launch_stem(op, in, out, B, st);
         }
+        case ROMP_OP_BEV_PACK: {
+            const float* fv = resolve_in(n, op.in_buf, image);
+            const float* ft = resolve_in(n, op.res_buf, image);
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(fv && ft && out, "bev_pack: bad buffers");
+            return launch_bev_pack(fv, op.in_cstride, ft, op.res_cstride, out, B, st);
+        }
+        case ROMP_OP_BEV_MAPS: {
+            const float* fv = resolve_in(n, op.in_buf, image);
+            const float* bv = resolve_in(n, op.res_buf, image);
+            float* c3 = resolve_out(n, op.out_buf, center, params);
+            float* cam = resolve_out(n, op.term_buf[0], center, params);
+            ROMP_REQUIRE(fv && bv && c3 && cam && op.weight, "bev_maps: bad buffers");
+            return launch_bev_maps(fv, op.in_cstride, bv, op.res_cstride, op.weight, c3, cam, B, st);
+        }
+        case ROMP_OP_CONV3D: {
+            const float* in = resolve_in(n, op.in_buf, image);
+            const float* res = op.res_buf == ROMP_BUF_NONE ? nullptr : resolve_in(n, op.res_buf, image);
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(in && out && op.weight && op.scale && op.shift, "conv3d: bad buffers");
+            return launch_conv3d(op.Cin, op.weight, op.scale, op.shift, op.relu, in, res, out, B, st);
+        }
         case ROMP_OP_CONV: {
+            if (op.ksize == 13) {
+                // Conv1d k=3 along W over B independent sequences: one "image" whose rows are the batch
+                const float* in1 = resolve_in(n, op.in_buf, image);
+                float* out1 = resolve_out(n, op.out_buf, center, params);
+                ROMP_REQUIRE(in1 && out1 && op.res_buf == ROMP_BUF_NONE, "conv1d: bad buffers");
+                romp_op o1 = op;
+                o1.H = B;
+                return launch_conv(o1, in1, nullptr, out1, 1, n->mode, variant, n->queues + idx * 8, st);
+            }
             const float* in = resolve_in(n, op.in_buf, image);
             float* out = resolve_out(n, op.out_buf, center, params);
             const float* res = op.res_buf == ROMP_BUF_NONE ? nullptr : resolve_in(n, op.res_buf, image);
@@ -354,6 +385,11 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     ROMP_REQUIRE(op->kind == ROMP_OP_CONV, "romp_conv_describe: op kind %d", op->kind);
     if (variant >= 0 && !conv_variant_valid(*op, variant)) { set_error("variant %d not valid for this op", variant); return ROMP_EINVAL; }
     return describe_conv(*op, B, variant, out, n);
+}
+
+float* romp_net_buffer_ptr(romp_net* n, int buf) {
+    if (!n || buf < 0 || buf >= (int)n->bufs.size()) return nullptr;
+    return n->bufs[buf];
 }
 
 int romp_net_tuned_variant(romp_net* n, int B, int op_index) {

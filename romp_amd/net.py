@@ -14,7 +14,10 @@ from .plan import Program, build_romp_hrnet32, coord_channels
 
 
 class RompNet:
-    def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False):
+    def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
+                 out_shapes=None):
+        """`builder(state_dict, device, input_size) -> Program` (default: ROMP HRNet-32 + head);
+        `out_shapes`: per-image shapes of the two output tensors of the program."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
@@ -22,17 +25,20 @@ class RompNet:
         self.max_batch = int(max_batch)
         self.input_size = input_size
         with torch.cuda.device(self.device):
-            self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size)
+            self.program: Program = (builder or build_romp_hrnet32)(state_dict, self.device, input_size)
             ops = self.program.op_array()
             sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
             h = C.c_void_p()
             L.check(self.lib.romp_net_create(C.byref(h), ops, len(self.program.ops), sizes,
                                              len(self.program.buf_floats), self.max_batch))
             self._h = h
-            fs = input_size // 4
-            coords = coord_channels(self.max_batch, fs, self.device)
-            L.check(self.lib.romp_net_write_buffer(self._h, self.program.head_in_buf, L.ptr(coords),
-                                                   coords.numel(), L.stream_ptr(self.device)))
+            ms = input_size // 8
+            self.out_shapes = out_shapes or ((ms, ms), (ms, ms, 145))
+            if builder is None:      # ROMP head: constant CoordConv channels of the head input (model.py:473)
+                fs = input_size // 4
+                coords = coord_channels(self.max_batch, fs, self.device)
+                L.check(self.lib.romp_net_write_buffer(self._h, self.program.head_in_buf, L.ptr(coords),
+                                                       coords.numel(), L.stream_ptr(self.device)))
             torch.cuda.synchronize(self.device)
         if use_graph:
             self.set_graph(True)
@@ -55,11 +61,10 @@ class RompNet:
         assert image.dtype == torch.float32 and image.is_cuda and image.dim() == 4 and image.shape[-1] == 3
         image = image.contiguous()
         B = image.shape[0]
-        ms = self.input_size // 8
         if center_out is None:
-            center_out = torch.empty(B, ms, ms, device=self.device, dtype=torch.float32)
+            center_out = torch.empty((B,) + tuple(self.out_shapes[0]), device=self.device, dtype=torch.float32)
         if params_out is None:
-            params_out = torch.empty(B, ms, ms, 145, device=self.device, dtype=torch.float32)
+            params_out = torch.empty((B,) + tuple(self.out_shapes[1]), device=self.device, dtype=torch.float32)
         L.check(self.lib.romp_net_forward(self._h, L.ptr(image), B, L.ptr(center_out), L.ptr(params_out),
                                           L.stream_ptr(self.device)))
         return center_out, params_out
@@ -84,6 +89,10 @@ class RompNet:
             names.append(buf.value.decode())
         return names
 
+    def buffer_ptr(self, buf):
+        """Device address of arena buffer `buf`."""
+        return self.lib.romp_net_buffer_ptr(self._h, int(buf))
+
     def read_buffer(self, buf, B):
         n = self.program.buf_floats[buf] * B
         out = torch.empty(n, device=self.device, dtype=torch.float32)
@@ -93,9 +102,8 @@ class RompNet:
     def profile(self, image, iters=3):
         """Per-op mean milliseconds (HIP events on the current stream)."""
         B = image.shape[0]
-        ms = self.input_size // 8
-        c = torch.empty(B, ms, ms, device=self.device)
-        p = torch.empty(B, ms, ms, 145, device=self.device)
+        c = torch.empty((B,) + tuple(self.out_shapes[0]), device=self.device)
+        p = torch.empty((B,) + tuple(self.out_shapes[1]), device=self.device)
         out = (C.c_float * len(self.program.ops))()
         L.check(self.lib.romp_net_profile(self._h, L.ptr(image.contiguous()), B, L.ptr(c), L.ptr(p),
                                           L.stream_ptr(self.device), out, iters))

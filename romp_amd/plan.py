@@ -18,8 +18,8 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_CONV, OP_FORK, OP_FUSESUM, OP_JOIN, OP_STEM,
-                  RompOp)
+from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_BEV_MAPS, OP_BEV_PACK, OP_CONV, OP_CONV3D, OP_FORK,
+                  OP_FUSESUM, OP_JOIN, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
 HEAD_IN_CH = 40          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 8
@@ -60,18 +60,21 @@ def conv_pads(cin, cout, ksize):
     cout to the 32-wide MFMA N-block (64 when the layer has >= 64 channels)."""
     if ksize == 1:
         ck = 32 if cin % 32 == 0 else 16
-    else:
+    else:                                   # 3 (3x3) and 13 (1x3, Conv1d)
         ck = 16 if cin % 16 == 0 else 8
     return _round_up(cin, ck), _round_up(cout, 64 if cout >= 64 else 32)
 
 
 def pack_conv_weight(w, cin_pad, cout_pad):
-    """OIHW (cout,cin,k,k) -> [tap][cin_pad/4][cout_pad][4] (zero padded)."""
-    cout, cin, k, _ = w.shape
-    t = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
-    full = torch.zeros(k * k, cin_pad, cout_pad, dtype=torch.float32)
+    """OIHW (cout,cin,kh,kw) -> [tap][cin_pad/4][cout_pad][4] (zero padded); Conv1d weights
+    (cout,cin,3) are treated as kh=1, kw=3."""
+    if w.dim() == 3:
+        w = w.unsqueeze(2)
+    cout, cin, kh, kw = w.shape
+    t = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    full = torch.zeros(kh * kw, cin_pad, cout_pad, dtype=torch.float32)
     full[:, :cin, :cout] = t
-    return full.reshape(k * k, cin_pad // 4, 4, cout_pad).permute(0, 1, 3, 2).contiguous()
+    return full.reshape(kh * kw, cin_pad // 4, 4, cout_pad).permute(0, 1, 3, 2).contiguous()
 
 
 class Program:
@@ -168,8 +171,9 @@ class Program:
         for g in range(groups):
             ps[g, :cout], pb[g, :cout] = scale[g], shift[g]
         pw, ps, pb = self._dev(pw), self._dev(ps), self._dev(pb)
-        Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
-        Wo = (x.W + 2 * (ksize // 2) - ksize) // stride + 1
+        kh, kw = (1, 3) if ksize == 13 else (ksize, ksize)
+        Ho = (x.H + 2 * (kh // 2) - kh) // stride + 1
+        Wo = (x.W + 2 * (kw // 2) - kw) // stride + 1
         if out is None and out_buf_special is None:
             out = self.new_act(cout * groups, Ho, Wo)
         op = RompOp()
@@ -189,7 +193,7 @@ class Program:
         op.stream = self.cur_stream
         self.ops.append(op)
         self.names.append(name)
-        self.flops.append(2.0 * Ho * Wo * cout * cin * ksize * ksize * groups)
+        self.flops.append(2.0 * Ho * Wo * cout * cin * kh * kw * groups)
         nbytes = 4.0 * (x.H * x.W * cin_phys * groups + Ho * Wo * cout * groups * (2 if res is not None else 1))
         self.bytes.append(nbytes)
         return out
@@ -238,10 +242,13 @@ class Program:
         return arr
 
 
-def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> Program:
-    """state_dict of ROMPv1 (model.py:420-481) -> Program."""
-    sd = {k: v.detach().float().cpu() for k, v in sd.items() if not k.endswith('num_batches_tracked')}
-    P = Program(device)
+def _clean(sd):
+    return {k: v.detach().float().cpu() for k, v in sd.items() if not k.endswith('num_batches_tracked')}
+
+
+def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Act:
+    """HigherResolutionNet (model.py:246-417) -> ops in P; returns the 32-channel 1/4-resolution output
+    (written with channel stride `out_cstride` into a persistent buffer)."""
 
     def cbr(name, x, conv, bn, k, stride, relu, res=None, out=None):
         w = sd[conv + '.weight']
@@ -339,12 +346,22 @@ def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> P
           cbr('transition3.3', xs[-1], bb + 'transition3.3.0.0', bb + 'transition3.3.0.1', 3, 2, True)]
     for m in range(2):
         xs = hr_module(f'{bb}stage4.{m}.', xs, 4)
-    # last module emits branch 0 only -> straight into the head input buffer (32 of 40 channels);
-    # channels 32,33 hold the constant CoordConv maps (model.py:473), 34..39 are zero padding.
+    # last module emits branch 0 only -> straight into the (persistent) head input buffer
     fs = input_size // 4
-    P.head_in_buf = P.alloc(HEAD_IN_CH * fs * fs, persistent=True)
-    head_in = Act(P.head_in_buf, 32, fs, fs, HEAD_IN_CH)
+    P.head_in_buf = P.alloc(out_cstride * fs * fs, persistent=True)
+    head_in = Act(P.head_in_buf, 32, fs, fs, out_cstride)
     hr_module(f'{bb}stage4.2.', xs, 1, final_out=head_in)
+    return head_in
+
+
+def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> Program:
+    """state_dict of ROMPv1 (model.py:420-481) -> Program."""
+    sd = _clean(sd)
+    P = Program(device)
+    # backbone output lands in 32 of the 40 channels of the head input buffer; channels 32,33 hold the
+    # constant CoordConv maps (model.py:473), 34..39 are zero padding.
+    build_hrnet32_backbone(P, sd, input_size, out_cstride=HEAD_IN_CH)
+    fs = input_size // 4
     head_x = Act(P.head_in_buf, HEAD_IN_CH, fs, fs, HEAD_IN_CH)
 
     # ---- head (model.py:445-481): the three towers share their input; first conv runs as one
