@@ -191,6 +191,21 @@ void smpl_ctx_destroy(smpl_ctx* ctx);
 int  romp_project(const float* joints, int N, int J, const float* cam, const float* pad_info_host,
                   float* pj2d, float* pj2d_org, float* cam_trans, void* stream);
 
+/* ------------------------------------------------------------------ callers either side */
+
+/* img_preprocess (utils.py:16-30) on device: BGR uint8 (H,W,3) -> RGB float32 (S,S,3) 0..255, centred zero
+ * pad to square + bicubic resize (OpenCV INTER_CUBIC convention, float arithmetic).  pad_info_host[6]
+ * receives top,bottom,left,right,h,w. */
+int  romp_preprocess(const unsigned char* bgr_u8, int H, int W, float* out_rgb_f32, int out_size,
+                     float* pad_info_host, void* stream);
+/* BEV per-image post-processing (bev/post_parser.py:68-136,167-222): camera translation, perspective
+ * projection (normalised and original-image pixels), projection-based duplicate suppression, outlier
+ * removal.  Persons of image b are rows offsets[b]..offsets[b+1]-1 (offsets: B+1 int32, device);
+ * pad_info: (B,6) device.  keep[row] = 1 if the person survives. */
+int  romp_bev_postprocess(const float* joints /* (N,71,3) */, const float* cam /* (N,3) */, const int32_t* offsets,
+                          int B, const float* pad_info, float nms_thresh, float relative_scale_thresh,
+                          float* pj2d, float* pj2d_org, float* cam_trans, int32_t* keep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

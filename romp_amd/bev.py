@@ -5,10 +5,10 @@ and of the device-side steps of ``BEVv1.forward`` (bev/model.py:232-250) for BAS
     model = bev.BEV(bev.bev_settings([]), state_dict=..., smpla_model=..., smil_model=...)
     outputs = model(bgr_image)         # dict of numpy arrays, or None
 
-Network (HRNet-32 + BEV head), 3-D center parsing, per-person regression, SMPL-A / SMIL meshes all
-run in libromp_hip.so.  Not built yet (SURVEY.md §8f-2 "next"): perspective projection of the joints,
-projection-based duplicate suppression and outlier removal (bev/post_parser.py:68-107,167-222), and
-the long-image "crowd" sliding window (bev/main.py:184-258, CPU orchestration).
+Network (HRNet-32 + BEV head), 3-D center parsing, per-person regression, SMPL-A / SMIL meshes,
+perspective projection, projection-based duplicate suppression and outlier removal
+(bev/post_parser.py:68-136,167-222) all run in libromp_hip.so.  Not built: the long-image "crowd"
+sliding window (bev/main.py:184-258, CPU orchestration of repeated single forwards).
 """
 import argparse
 import ctypes as C
@@ -23,7 +23,7 @@ from . import lib as L
 from .bev_plan import DEPTH, MAP, build_bev_hrnet32, cam3dmap_anchor
 from .net import RompNet
 from .smpl import SMPL
-from .utils import convert_tensor2numpy, determine_device, img_preprocess
+from .utils import convert_tensor2numpy, determine_device, img_preprocess_device
 
 
 def bev_settings(input_args=sys.argv[1:]):
@@ -179,8 +179,10 @@ class BEV(nn.Module):
         self.result_keys = ['smpl_thetas', 'smpl_betas', 'cam', 'cam_trans', 'params_pred', 'center_confs', 'pred_batch_ids']
 
     @torch.no_grad()
-    def forward_batch(self, images):
-        """[extension] images (B,512,512,3) float on device -> dict of device tensors or None."""
+    def forward_batch(self, images, pad_infos=None):
+        """[extension] images (B,512,512,3) float on device -> dict of device tensors or None.
+        With `pad_infos` (B,6) the per-image post-processing of process_normal_image (bev/main.py:168-180)
+        runs too: projection, duplicate suppression, outlier removal (rows of dropped persons removed)."""
         out = self.model(images)
         if out is None:
             return None
@@ -188,12 +190,35 @@ class BEV(nn.Module):
         if self.settings.calc_smpl:
             verts, joints, face = self.smpl_parser(res['smpl_betas'], res['smpl_thetas'])
             res.update({'verts': verts, 'joints': joints})
+            if pad_infos is not None:
+                res = self._postprocess(res, images.shape[0], pad_infos)
         return res
+
+    def _postprocess(self, res, B, pad_infos):
+        lib = L.load()
+        dev = self.tdevice
+        N = res['cam'].shape[0]
+        counts = torch.bincount(res['pred_batch_ids'], minlength=B)
+        offsets = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        offsets[1:] = torch.cumsum(counts, 0).int()
+        pads = torch.as_tensor(pad_infos, dtype=torch.float32).reshape(B, 6).to(dev).contiguous()
+        pj = torch.empty(N, 71, 2, device=dev)
+        pjo = torch.empty(N, 71, 2, device=dev)
+        tr = torch.empty(N, 3, device=dev)
+        keep = torch.empty(N, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.romp_bev_postprocess(L.ptr(res['joints'].contiguous()), L.ptr(res['cam'].contiguous()), L.ptr(offsets),
+                                             B, L.ptr(pads), float(self.settings.nms_thresh),
+                                             float(self.settings.relative_scale_thresh), L.ptr(pj), L.ptr(pjo), L.ptr(tr),
+                                             L.ptr(keep), L.stream_ptr(dev)))
+        res.update({'cam_trans': tr, 'pj2d': pjo, 'pj2d_org': pjo})       # the reference aliases pj2d to pj2d_org
+        mask = keep.bool()
+        return {k: (v[mask] if torch.is_tensor(v) and v.shape[:1] == (N,) else v) for k, v in res.items()}
 
     def forward(self, image, signal_ID=0, **kwargs):
         """bev/main.py:139-181 (normal images): BGR uint8 HxWx3 -> dict of numpy arrays or None."""
-        input_image, image_pad_info = img_preprocess(image)
-        res = self.forward_batch(input_image.to(self.tdevice))
+        input_image, image_pad_info = img_preprocess_device(image, self.tdevice)
+        res = self.forward_batch(input_image, image_pad_info.reshape(1, 6))
         if res is None:
             return None
         return convert_tensor2numpy(res)

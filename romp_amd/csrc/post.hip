@@ -1,0 +1,174 @@
+// post.hip -- the callers either side of the network (SURVEY.md §8f "next" rows 1 and 2):
+//
+//  * preprocess_kernel: img_preprocess (simple_romp/romp/utils.py:16-30) on device -- BGR->RGB,
+//    centred zero pad to a square, bicubic resize to 512x512 (OpenCV INTER_CUBIC convention: pixel
+//    centres, a = -0.75, replicated border), round + saturate to uint8, -> float32 (1,512,512,3).
+//    The caller uploads the uint8 frame (0.25 B/px/ch) instead of the float tensor (4x the bytes).
+//    OpenCV's fixed-point rounding is not reproduced (cv2 is a third-party dependency that is not
+//    available to pin against): parity is against the float restatement in romp_amd/utils.py.
+//
+//  * bev_post_kernel: BEV's per-image post-processing (simple_romp/bev/post_parser.py):
+//    denormalize_cam_params_to_trans :114-128, perspective_projection :68-107 (+ to-original-image
+//    :129-136), suppressing_redundant_prediction_via_projection :167-198, remove_outlier :200-222.
+//    One workgroup per image; persons of an image are contiguous rows.  Output: projections and a
+//    keep mask (the caller drops the rows).
+#include "common.h"
+
+namespace romp {
+
+__device__ __forceinline__ void cubic_coeffs(float fx, float* c) {
+    const float A = -0.75f;
+    c[0] = ((A * (fx + 1.f) - 5.f * A) * (fx + 1.f) + 8.f * A) * (fx + 1.f) - 4.f * A;
+    c[1] = ((A + 2.f) * fx - (A + 3.f)) * fx * fx + 1.f;
+    c[2] = ((A + 2.f) * (1.f - fx) - (A + 3.f)) * (1.f - fx) * (1.f - fx) + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+__global__ void preprocess_kernel(const unsigned char* __restrict__ src, int H, int W, int side, int top, int left,
+                                  float* __restrict__ dst, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * S) return;
+    const int ox = i % S, oy = i / S;
+    const float scale = (float)side / (float)S;
+    const float fy = (oy + 0.5f) * scale - 0.5f, fx = (ox + 0.5f) * scale - 0.5f;
+    const int sy = (int)floorf(fy), sx = (int)floorf(fx);
+    float cy[4], cx[4];
+    cubic_coeffs(fy - sy, cy);
+    cubic_coeffs(fx - sx, cx);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int a = 0; a < 4; ++a) {
+        const int py = min(max(sy - 1 + a, 0), side - 1) - top;          // replicated border of the PADDED image
+        for (int b = 0; b < 4; ++b) {
+            const int px = min(max(sx - 1 + b, 0), side - 1) - left;
+            if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+                const unsigned char* p = src + ((size_t)py * W + px) * 3;
+                const float wgt = cy[a] * cx[b];
+                acc[0] += wgt * p[2]; acc[1] += wgt * p[1]; acc[2] += wgt * p[0];   // BGR -> RGB
+            }
+        }
+    }
+    for (int c = 0; c < 3; ++c) dst[(size_t)i * 3 + c] = fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);
+}
+
+constexpr int PJ = 71, PMAX = 64;
+
+__global__ __launch_bounds__(256) void bev_post_kernel(const float* __restrict__ joints, const float* __restrict__ cam,
+                                                        const int* __restrict__ offsets, const float* __restrict__ pad_info,
+                                                        float nms_thresh, float rel_thresh, float scale_thresh,
+                                                        float* pj2d, float* pj2d_org, float* cam_trans, int* keep) {
+    __shared__ float s_pj[PMAX * PJ * 2];
+    __shared__ float s_scale[PMAX], s_tr[PMAX][3], s_mean[PMAX];
+    __shared__ int s_removed[PMAX], s_alive[PMAX], s_n_alive;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int off = offsets[b], n = min(offsets[b + 1] - off, PMAX);
+    if (n <= 0) return;
+    const float* pi = pad_info + b * 6;                       // top, bottom, left, right, h, w
+    const float top = pi[0], left = pi[2], pad_size = fmaxf(pi[4], pi[5]);
+    const float tan_fov = 0.57735026918962573f;
+    if (tid < n) {                                            // denormalize_cam_params_to_trans (:114-128)
+        const float* c = cam + (size_t)(off + tid) * 3;
+        const float depth = 1.f / (c[0] * tan_fov + 1e-3f);
+        s_tr[tid][0] = c[2] * depth * tan_fov; s_tr[tid][1] = c[1] * depth * tan_fov; s_tr[tid][2] = depth;
+        for (int k = 0; k < 3; ++k) cam_trans[(size_t)(off + tid) * 3 + k] = s_tr[tid][k];
+        s_scale[tid] = c[0] * 2.f;
+        s_removed[tid] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * PJ; i += 256) {                  // perspective_projection (:68-107), then to org image
+        const int p = i / PJ;
+        const float* j = joints + (size_t)(off * PJ + i) * 3;
+        const float z = (j[2] + s_tr[p][2]) + 1e-6f;
+        float x = (j[0] + s_tr[p][0]) / z * 443.4f, y = (j[1] + s_tr[p][1]) / z * 443.4f;
+        x /= 256.f; y /= 256.f;                                // normalize: /= img_size/2
+        pj2d[(size_t)(off * PJ + i) * 2] = x; pj2d[(size_t)(off * PJ + i) * 2 + 1] = y;
+        x = (x + 1.f) * pad_size / 2.f - left; y = (y + 1.f) * pad_size / 2.f - top;
+        s_pj[i * 2] = x; s_pj[i * 2 + 1] = y;
+        pj2d_org[(size_t)(off * PJ + i) * 2] = x; pj2d_org[(size_t)(off * PJ + i) * 2 + 1] = y;
+    }
+    __syncthreads();
+    // suppressing_redundant_prediction_via_projection (:167-198): pairs a<b closer than the threshold
+    if (n > 1) {
+        const float thr = nms_thresh * pad_size / 640.f;       // max(img_shape) == max(h,w) == pad size
+        for (int pr = tid; pr < n * n; pr += 256) {
+            const int a = pr / n, c = pr % n;
+            if (a >= c) continue;
+            float d = 0.f;
+            for (int k = 0; k < PJ; ++k) {
+                const float dx = s_pj[(a * PJ + k) * 2] - s_pj[(c * PJ + k) * 2];
+                const float dy = s_pj[(a * PJ + k) * 2 + 1] - s_pj[(c * PJ + k) * 2 + 1];
+                d += sqrtf(dx * dx + dy * dy);
+            }
+            d = d / PJ / fmaxf(s_scale[a], s_scale[c]);
+            if (d < thr) atomicExch(&s_removed[s_scale[a] < s_scale[c] ? a : c], 1);   // drop the smaller (farther) one
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int m = 0;
+        for (int p = 0; p < n; ++p)
+            if (!s_removed[p]) s_alive[m++] = p;
+        s_n_alive = m;
+    }
+    __syncthreads();
+    // remove_outlier (:200-222) on the survivors: mean distance to the others without the smallest and
+    // the largest entry of the row (sorted()[1:-1])
+    const int m = s_n_alive;
+    if (m >= 3) {
+        if (tid < m) {
+            const int a = s_alive[tid];
+            float sum = 0.f, mn = 3.4e38f, mx = -1.f;
+            for (int k = 0; k < m; ++k) {
+                const int c = s_alive[k];
+                const float dx = s_tr[a][0] - s_tr[c][0], dy = s_tr[a][1] - s_tr[c][1], dz = s_tr[a][2] - s_tr[c][2];
+                const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+                sum += d; mn = fminf(mn, d); mx = fmaxf(mx, d);
+            }
+            s_mean[tid] = (sum - mn - mx) / (m - 2);
+        }
+        __syncthreads();
+        if (tid < m) {
+            float tot = 0.f;
+            for (int k = 0; k < m; ++k) tot += s_mean[k];
+            const float rel = s_mean[tid] / ((tot - s_mean[tid]) / (m - 1));
+            const int a = s_alive[tid];
+            if (rel > rel_thresh && cam[(size_t)(off + a) * 3] < scale_thresh) s_removed[a] = 1;
+        }
+        __syncthreads();
+    }
+    if (tid < n) keep[off + tid] = !s_removed[tid];
+}
+
+}  // namespace romp
+
+using namespace romp;
+
+extern "C" {
+
+int romp_preprocess(const unsigned char* bgr_u8, int H, int W, float* out_rgb_f32, int out_size, float* pad_info_host,
+                    void* stream) {
+    ROMP_REQUIRE(bgr_u8 && out_rgb_f32 && H > 0 && W > 0 && out_size > 0, "romp_preprocess: bad arguments");
+    const int side = H > W ? H : W;
+    const int top = (side - H) / 2, left = (side - W) / 2;
+    if (pad_info_host) {
+        pad_info_host[0] = (float)top; pad_info_host[1] = (float)(top + H); pad_info_host[2] = (float)left;
+        pad_info_host[3] = (float)(left + W); pad_info_host[4] = (float)H; pad_info_host[5] = (float)W;
+    }
+    const int total = out_size * out_size;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, bgr_u8, H, W, side, top,
+                       left, out_rgb_f32, out_size);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+int romp_bev_postprocess(const float* joints, const float* cam, const int32_t* offsets, int B, const float* pad_info,
+                         float nms_thresh, float relative_scale_thresh, float* pj2d, float* pj2d_org, float* cam_trans,
+                         int32_t* keep, void* stream) {
+    ROMP_REQUIRE(joints && cam && offsets && pad_info && pj2d && pj2d_org && cam_trans && keep && B > 0,
+                 "romp_bev_postprocess: bad arguments");
+    hipLaunchKernelGGL(bev_post_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, joints, cam, offsets, pad_info, nms_thresh,
+                       relative_scale_thresh, 0.25f, pj2d, pj2d_org, cam_trans, keep);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+}  // extern "C"

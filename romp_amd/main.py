@@ -22,7 +22,7 @@ from . import lib as L
 from .net import RompNet
 from .post_parser import (CenterMap, SMPL_parser, body_mesh_projection2image, convert_cam_to_3d_trans,
                           parsing_outputs)
-from .utils import ResultSaver, convert_tensor2numpy, determine_device, img_preprocess
+from .utils import ResultSaver, convert_tensor2numpy, determine_device, img_preprocess, img_preprocess_device
 
 
 def romp_settings(input_args=sys.argv[1:]):
@@ -50,6 +50,7 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--root_align', type=bool, default=False, help='Please set this config as True to use the ROMP checkpoints trained by yourself.')
     parser.add_argument('--webcam_id', type=int, default=0, help='The Webcam ID.')
     parser.add_argument('--max_batch', type=int, default=32, help='[romp_amd] largest batch forward_batch will be called with')
+    parser.add_argument('--host_preprocess', action='store_true', help='[romp_amd] pad/resize on the host (cv2 / numpy) instead of the device kernel')
     args = parser.parse_args(input_args)
     if not torch.cuda.is_available():
         args.GPU = -1
@@ -96,8 +97,12 @@ class ROMP(nn.Module):
 
     def single_image_forward(self, image):
         """main.py:106-115."""
-        input_image, image_pad_info = img_preprocess(image)
-        center_maps, params_maps = self.model(input_image.to(self.tdevice))
+        if getattr(self.settings, 'host_preprocess', False):
+            input_image, image_pad_info = img_preprocess(image)            # reference path (cv2 / numpy on the host)
+            input_image = input_image.to(self.tdevice)
+        else:                                                              # uint8 upload + pad/resize on the device
+            input_image, image_pad_info = img_preprocess_device(image, self.tdevice)
+        center_maps, params_maps = self.model(input_image)
         parsed_results = parsing_outputs(center_maps, params_maps, self.centermap_parser)
         return parsed_results, image_pad_info
 

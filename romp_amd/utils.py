@@ -62,6 +62,22 @@ def img_preprocess(image, input_size=512):
     return torch.from_numpy(resized)[None].float(), image_pad_info
 
 
+def img_preprocess_device(image, device, input_size=512):
+    """img_preprocess on the HIP device (csrc/post.hip): uploads the uint8 BGR frame (1/4 of the bytes of
+    the float tensor) and pads / resizes / converts there.  -> ((1,S,S,3) float32 device tensor, pad info)."""
+    import ctypes as C
+    from . import lib as L
+    lib = L.load()
+    img = torch.from_numpy(np.ascontiguousarray(image)).to(device)
+    assert img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3
+    out = torch.empty(1, input_size, input_size, 3, device=device, dtype=torch.float32)
+    pad = (C.c_float * 6)()
+    with torch.cuda.device(device):
+        L.check(lib.romp_preprocess(L.ptr(img), int(img.shape[0]), int(img.shape[1]), L.ptr(out), input_size, pad,
+                                    L.stream_ptr(device)))
+    return out, torch.Tensor(list(pad))
+
+
 def convert_tensor2numpy(outputs, del_keys=('verts_camed', 'smpl_face', 'pj2d', 'verts_camed_org')):
     """utils.py:32-41."""
     for key in del_keys:

@@ -299,6 +299,7 @@ def test_romp_api_end_to_end(dev):
     import romp_amd
     settings = romp_amd.romp_settings([])
     settings.GPU, settings.center_thresh = 0, 1.25
+    settings.host_preprocess = True            # same pre-processed tensor as the oracle below (device path: test_bev_post.py)
     sd = O.make_romp_state_dict(0, center_bias=2.0)
     smpl_model = O.make_synthetic_smpl(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
@@ -327,6 +328,11 @@ def test_romp_api_end_to_end(dev):
     assert np.abs(out['verts'] - vo).max() < 1e-4 and np.abs(out['joints'] - jo).max() < 1e-4
     pj = O.project_to_org_image(O.batch_orth_proj(jo, out['cam']), pad.numpy())
     np.testing.assert_allclose(out['pj2d_org'], pj, atol=2e-2)
+    # device pre-processing path gives the same detections
+    settings.host_preprocess = False
+    out_d = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)(image)
+    assert np.array_equal(out_d['center_preds'], out['center_preds'])
+    assert np.abs(out_d['verts'] - out['verts']).max() < 5e-3
     # nobody above threshold -> None
     settings.center_thresh = 50.0
     model2 = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
