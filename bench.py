@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--center-thresh', type=float, default=1.3)
+    ap.add_argument('--workload', type=str, default='romp', choices=['romp', 'bev'],
+                    help="romp = BASELINE configs[1] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A)")
     ap.add_argument('--graph', type=int, default=1, help='replay the network from a hipGraph')
     ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
@@ -135,6 +137,42 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
                        '(reference onnxruntime path unavailable: module not installed)' % (n, Bc))
 
 
+def bench_bev(args, dev):
+    """BASELINE configs[3]: BEV HRNet-32 + bird's-eye-view head, 512x512, batch 32, 1 GPU (not the headline line)."""
+    from romp_amd import bev, synthetic as S
+    from oracle import bev_oracle as BO          # synthetic BEV weights only (generator lives with the oracle)
+    s = bev.bev_settings([])
+    s.GPU, s.max_batch = dev.index or 0, args.batch
+    sd = BO.make_bev_state_dict(0)
+    model = bev.BEV(s, state_dict=sd, smpla_model=S.make_smpl_model(0, 11), smil_model=S.make_smpl_model(5, 10))
+    images = S.make_images(args.batch, seed=4, device=dev)
+    # threshold giving ~12 persons per image on this synthetic input (cf. tests/golden/bev_b1.npz)
+    model.model.centermap_parser.conf_thresh = 0.6237
+    if args.autotune:
+        model.model.net.autotune(args.batch)
+    pads = torch.tensor([[0., 512., 0., 512., 512., 512.]]).repeat(args.batch, 1)
+    n = 0
+    for _ in range(args.warmup):
+        r = model.forward_batch(images, pads)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = model.forward_batch(images, pads)
+        n = 0 if r is None else r['cam'].shape[0]
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    ms = model.model.net.profile(images, iters=2)
+    print(json.dumps({'metric': 'images/sec (512x512, BEV HRNet-32)', 'value': round(args.batch * args.steps / dt, 2),
+                      'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+                      'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+                      'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                      'config': {'workload': 'BEV HRNet-32 + BEV head 512x512 batch=%d (BASELINE configs[3]); net+3D parse+'
+                                             'regression+SMPL-A+post-processing' % args.batch,
+                                 'persons_kept_per_image': round(n / args.batch, 2), 'net_ms_per_batch': round(sum(ms), 3),
+                                 'head_ms_per_batch': round(sum(t for t, nm in zip(ms, model.model.net.program.names) if nm.startswith('bev.')), 3)}}),
+          flush=True)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -150,6 +188,8 @@ def main():
     import romp_amd
     from romp_amd import lib as L, synthetic as S, distributed as D
     lib = L.load()
+    if args.workload == 'bev':
+        return bench_bev(args, dev)
     settings = romp_amd.romp_settings([])
     settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
     sd = S.make_romp_state_dict(0)
