@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument('--workload', type=str, default='romp', choices=['romp', 'bev'],
                     help="romp = BASELINE configs[1] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A)")
     ap.add_argument('--graph', type=int, default=1, help='replay the network from a hipGraph')
+    ap.add_argument('--conv-math', type=str, default='f32', choices=['f32', 'bf16x3'],
+                    help='f32: exact f32 MFMA kernels only; bf16x3: also offer the f32-accurate bf16x3-split kernels to the autotuner')
     ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -192,6 +194,7 @@ def main():
         return bench_bev(args, dev)
     settings = romp_amd.romp_settings([])
     settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
+    settings.conv_math = args.conv_math
     sd = S.make_romp_state_dict(0)
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
@@ -243,7 +246,7 @@ def main():
         'config': {'workload': 'ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); '
                                'net+parse+SMPL%s' % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'persons_per_image': round(persons / (B * world), 2),
-                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'parallelism': 'dp%d' % world},
+                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math, 'parallelism': 'dp%d' % world},
     }
     if rank == 0:
         if not args.no_roofline:

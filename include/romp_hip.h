@@ -87,6 +87,8 @@ typedef struct romp_op {
     const float* weight;          /* packed [group][chunk][tap][cin/4][cout_pad][4]       */
     const float* scale;           /* [group][cout_pad]  gamma/sqrt(var+eps)  (or 1)       */
     const float* shift;           /* [group][cout_pad]  beta-mean*scale (+scale*bias)     */
+    const void*  weight_aux;      /* optional: the same weights split into 3 bf16 pieces,
+                                     [group][tap][cin_pad/16][piece 3][kg 2][cout_pad][8] (bf16x3 kernels) */
 } romp_op;
 
 typedef struct romp_net romp_net;

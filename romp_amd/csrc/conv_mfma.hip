@@ -36,6 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvParams {
     const float* in; const float* w; const float* scale; const float* shift; const float* res;
     float* out;
+    const uint4* w3;          // bf16x3-split weights (conv_bx3_kernel), or nullptr
     int* queue;               // 8 per-XCD work counters, zeroed before the launch
     int H, W, Ho, Wo;
     int Cout;                 // valid output channels per group (store mask)
@@ -523,6 +524,245 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3 variant: the same persistent implicit GEMM, but every f32 operand is split into three bf16
+// pieces (x = x1 + x2 + x3 exactly: 3 x 8 significand bits) and the product is formed on the bf16
+// matrix pipe from the six piece products with weight >= 2^-16 -- x1w1, x1w2, x2w1, x1w3, x2w2, x3w1
+// (the dropped ones are below the f32 rounding of the product) -- accumulated in f32 by the MFMA.
+// Result: f32-accurate convolution (same parity gates as the f32-MFMA kernel) at 6 x 32 cycles per
+// 32x32x16 block instead of 8 x 64 cycles: 2.67x the f32 matrix rate.  Activations stay f32 in HBM;
+// they are split while being staged into LDS, the weights are pre-split on the host
+// (plan.py:pack_conv_weight_bx3).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KS, int S, int MT, int NT, int TW, int CK>
+struct BxCfg {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    static constexpr int K16 = CK / 16;
+    static constexpr int PSB = 3 * CK * 2 + 16;            // LDS bytes per pixel: 3 pieces x CK bf16 (+16 pad)
+    static constexpr int A_BYTES = C::HR * C::HC * PSB;
+    static constexpr int B_UNITS = C::TAPS * 3 * K16 * 2 * C::NW;      // 16-byte units: [tap][piece][k16][kg][NW]
+    static constexpr int NB = (B_UNITS + 255) / 256;
+    static constexpr int LDS_BYTES = A_BYTES + B_UNITS * 16 + 4 * C::NW * 4 + 16;
+};
+
+__device__ __forceinline__ void split3(float x, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
+    const __bf16 b1 = (__bf16)x;
+    const float r1 = x - (float)b1;                        // exact
+    const __bf16 b2 = (__bf16)r1;
+    const float r2 = r1 - (float)b2;                       // exact
+    const __bf16 b3 = (__bf16)r2;
+    p1 = __builtin_bit_cast(unsigned short, b1);
+    p2 = __builtin_bit_cast(unsigned short, b2);
+    p3 = __builtin_bit_cast(unsigned short, b3);
+}
+
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__device__ __forceinline__ void mma_stage_bx3(const char* sA, const char* sB, const int (&xoff)[MT], int woff,
+                                              f32x16 (&acc)[MT][NT]) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    using X = BxCfg<KS, S, MT, NT, TW, CK>;
+    constexpr int STEPS = C::TAPS * X::K16;
+    constexpr bool DB = MT * NT <= 2;                  // register double-buffer of the fragments only for small tiles
+    bf16x8 xf[DB ? 2 : 1][MT][3], wf[DB ? 2 : 1][NT][3];
+    auto load = [&](int step, int buf) {
+        const int tap = step / X::K16, k16 = step % X::K16;
+        const int dy = tap / C::KW, dx = tap % C::KW;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                xf[buf][m][pc] = *reinterpret_cast<const bf16x8*>(sA + xoff[m] + (dy * C::HC + dx) * X::PSB + pc * (CK * 2) + k16 * 32);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                wf[buf][n][pc] = *reinterpret_cast<const bf16x8*>(sB + woff + ((((tap * 3 + pc) * X::K16 + k16) * 2) * C::NW + n * 32) * 16);
+    };
+    if (DB) load(0, 0);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int cb = DB ? (step & 1) : 0;
+        if (DB) {
+            if (step + 1 < STEPS) load(step + 1, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            load(step, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {                // smallest terms first
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][n][2], xf[cb][m][0], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][n][1], xf[cb][m][1], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][n][0], xf[cb][m][2], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][n][1], xf[cb][m][0], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][n][0], xf[cb][m][1], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][n][0], xf[cb][m][0], acc[m][n], 0, 0, 0);
+            }
+        if (DB) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    using X = BxCfg<KS, S, MT, NT, TW, CK>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sA = reinterpret_cast<char*>(smem);          // haloed pixels, 3 bf16 pieces per channel
+    char* sB = sA + X::A_BYTES;                        // weight slab (pre-split)
+    float* sS = reinterpret_cast<float*>(sB + X::B_UNITS * 16);
+    int* sQ = reinterpret_cast<int*>(sS + 4 * C::NW);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
+    const int n_chunks = p.cin_pad / CK;
+
+    if (tid == 0) {
+        sQ[0] = atomicAdd(p.queue + q, 1);
+        sQ[1] = atomicAdd(p.queue + q, 1);
+    }
+    __syncthreads();
+    int j_cur = sQ[0], j_next = sQ[1];
+    if (j_cur >= p.per_queue) return;
+
+    float4 ra[C::NA];
+    uint4 rb[X::NB];
+    float rs = 0.f;
+
+    auto issue_loads = [&](const Item& it, int c0) {
+        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
+        const uint4* wg = p.w3 + (size_t)it.g * (C::TAPS * (p.cin_pad >> 4) * 6 * p.cout_pad);
+        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
+#pragma unroll
+        for (int k = 0; k < C::NA; ++k) {
+            const int idx = tid + k * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < C::A_VEC) {
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                const int hx = pix % C::HC, hy = pix / C::HC;
+                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
+                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
+            }
+            ra[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < X::NB; ++k) {
+            const int idx = tid + k * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (idx < X::B_UNITS) {
+                // LDS unit index: ((((tap*3 + pc)*K16 + k16)*2 + kg)*NW + j
+                int r = idx;
+                const int j = r % C::NW; r /= C::NW;
+                const int kg = r & 1; r >>= 1;
+                const int k16 = r % X::K16; r /= X::K16;
+                const int pc = r % 3;
+                const int tap = r / 3;
+                // global: [tap][cin_pad/16][piece][kg][cout_pad] units
+                v = wg[(unsigned)(((((tap * (p.cin_pad >> 4) + (c0 >> 4) + k16) * 3 + pc) * 2 + kg) * p.cout_pad) + it.n0 + j)];
+            }
+            rb[k] = v;
+        }
+        if (c0 == 0 && tid < 2 * C::NW) {
+            const float* src = tid < C::NW ? p.scale : p.shift;
+            rs = src[it.g * p.cout_pad + it.n0 + (tid & (C::NW - 1))];
+        }
+    };
+    auto write_lds = [&](bool first_chunk, int slot) {
+#pragma unroll
+        for (int k = 0; k < C::NA; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < C::A_VEC) {
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                unsigned short h[4][3];
+                split3(ra[k].x, h[0][0], h[0][1], h[0][2]);
+                split3(ra[k].y, h[1][0], h[1][1], h[1][2]);
+                split3(ra[k].z, h[2][0], h[2][1], h[2][2]);
+                split3(ra[k].w, h[3][0], h[3][1], h[3][2]);
+                char* dst = sA + pix * X::PSB + qq * 8;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    uint2 u;
+                    u.x = (unsigned)h[0][pc] | ((unsigned)h[1][pc] << 16);
+                    u.y = (unsigned)h[2][pc] | ((unsigned)h[3][pc] << 16);
+                    *reinterpret_cast<uint2*>(dst + pc * (CK * 2)) = u;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < X::NB; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < X::B_UNITS) *reinterpret_cast<uint4*>(sB + idx * 16) = rb[k];
+        }
+        if (first_chunk && tid < 2 * C::NW) sS[slot * 2 * C::NW + tid] = rs;
+    };
+
+    int xoff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mb = wave * MT + m;
+        const int row = mb * C::RPB + li / TW, col = li % TW;
+        xoff[m] = ((row * S) * C::HC + col * S) * X::PSB + lh * 16;
+    }
+    const int woff = (lh * C::NW + li) * 16;
+
+    Item cur = decode_item(p, q, j_cur, C::NW);
+    issue_loads(cur, 0);
+    write_lds(true, 0);
+    __syncthreads();
+    int slot = 0, ch = 0;
+    Item nxt = cur;
+    bool have_next = j_next < p.per_queue;
+    if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+    int j_after = 0x7fffffff;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+#pragma unroll 1
+    while (true) {
+        const bool last = ch + 1 == n_chunks;
+        const bool pf = !last || have_next;
+        Item tgt = last ? nxt : cur;
+        const int c0 = last ? 0 : (ch + 1) * CK;
+        if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
+        if (pf) issue_loads(tgt, c0);
+        mma_stage_bx3<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
+        if (ch == 0 && tid == 0) sQ[0] = j_after;
+        __syncthreads();
+        if (pf) write_lds(last, slot ^ 1);
+        if (last) {
+            conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        }
+        if (last && !have_next) break;
+        __syncthreads();
+        if (last) {
+            cur = nxt;
+            slot ^= 1;
+            ch = 0;
+            j_next = sQ[0];
+            have_next = j_next < p.per_queue;
+            if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+        } else {
+            ++ch;
+        }
+    }
+}
+
 // Bring-up cross-check: one thread per output element, same packed weights, plain FMA loop.
 __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups) {
     const size_t total = (size_t)B * p.Ho * p.Wo * p.Cout * groups;
@@ -556,14 +796,17 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
 // dispatch
 // ------------------------------------------------------------------------------------------------
 typedef void (*conv_fn)(ConvParams);
-struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; };
+struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; };
 
 #define ROMP_CONV_VARIANT(KS, S, MT, NT, TW, CK)                                      \
     { KS, S, MT, NT, TW, CK, conv_mfma_kernel<KS, S, MT, NT, TW, CK>,                 \
-      ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0 }
+      ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 0 }
 #define ROMP_CONV_VARIANT_PP(KS, S, MT, NT, TW, CK)                                   \
     { KS, S, MT, NT, TW, CK, conv_pp_kernel<KS, S, MT, NT, TW, CK>,                   \
-      2 * ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 1 }
+      2 * ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 1, 0 }
+#define ROMP_CONV_VARIANT_BX3(KS, S, MT, NT, TW, CK)                                  \
+    { KS, S, MT, NT, TW, CK, conv_bx3_kernel<KS, S, MT, NT, TW, CK>,                  \
+      BxCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 1 }
 
 static ConvVariant kVariants[] = {
     // 3x3 stride 1
@@ -587,6 +830,14 @@ static ConvVariant kVariants[] = {
     // 1x3 (Conv1d k=3: BEV bird's-eye-view head, bev/model.py:24-45,179-182)
     ROMP_CONV_VARIANT(13, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 1, 32, 16),
     ROMP_CONV_VARIANT(13, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 2, 32, 32),
+    // bf16x3 split (f32-accurate on the bf16 matrix pipe)
+    ROMP_CONV_VARIANT_BX3(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_BX3(3, 1, 2, 1, 16, 16),
+    ROMP_CONV_VARIANT_BX3(3, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_BX3(3, 1, 2, 2, 16, 16),
+    ROMP_CONV_VARIANT_BX3(3, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_BX3(3, 1, 1, 2, 16, 16),
+    ROMP_CONV_VARIANT_BX3(3, 1, 4, 1, 32, 16), ROMP_CONV_VARIANT_BX3(3, 1, 1, 1, 16, 16),
+    ROMP_CONV_VARIANT_BX3(3, 2, 1, 2, 16, 16), ROMP_CONV_VARIANT_BX3(3, 2, 1, 1, 16, 16), ROMP_CONV_VARIANT_BX3(3, 2, 1, 2, 32, 16),
+    ROMP_CONV_VARIANT_BX3(1, 1, 2, 2, 32, 32), ROMP_CONV_VARIANT_BX3(1, 1, 2, 1, 32, 32), ROMP_CONV_VARIANT_BX3(1, 1, 1, 2, 16, 32),
+    ROMP_CONV_VARIANT_BX3(1, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_BX3(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_BX3(13, 1, 2, 2, 32, 16),
     // ping-pong (8 waves, two alternating groups)
     ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 16, 16),
     ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 16, 16),
@@ -628,6 +879,7 @@ static int ensure_attrs() {
 
 static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) {
     if (v.lds > kMaxLds) return false;
+    if (v.math == 1 && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.ks != op.ksize || v.s != op.stride) return false;
     if (Wo % v.tw) return false;                     // rows may be partial (masked), columns may not
     if (op.cin_pad % v.ck || op.cout_pad % (v.nt * 32)) return false;
@@ -640,7 +892,7 @@ static int choose_variant(const romp_op& op, int Ho, int Wo, int B) {
     double best_score = -1;
     for (int i = 0; i < kNumVariants; ++i) {
         const ConvVariant& v = kVariants[i];
-        if (!variant_ok(v, op, Ho, Wo)) continue;
+        if (!variant_ok(v, op, Ho, Wo) || v.math) continue;     // bf16x3 variants are chosen by autotune / explicitly
         const long items = (long)B * ((Ho + v.th - 1) / v.th) * (Wo / v.tw) * (op.cout_pad / (v.nt * 32)) * op.groups;
         const double eff = (double)Ho / (((Ho + v.th - 1) / v.th) * v.th);   // partial row tiles waste MFMA work
         double fill = items >= 512 ? 1.0 : (double)items / 512.0;
@@ -674,6 +926,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
                  "conv: input channels must be float4 aligned (cs %d co %d Cin %d)", op.in_cstride, op.in_coff, op.Cin);
     ConvParams p;
     p.in = in; p.w = op.weight; p.scale = op.scale; p.shift = op.shift; p.res = res; p.out = out;
+    p.w3 = reinterpret_cast<const uint4*>(op.weight_aux);
     p.H = op.H; p.W = op.W;
     out_dims(op, &p.Ho, &p.Wo);
     p.Cout = op.Cout; p.cin_valid = op.Cin; p.cin_pad = op.cin_pad; p.cout_pad = op.cout_pad;
@@ -731,7 +984,8 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.pp ? "conv_pp" : "conv_mfma", v.ks, v.s, v.mt, v.nt, v.tw, v.ck);
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+             v.tw, v.ck);
     return ROMP_OK;
 }
 

@@ -30,7 +30,7 @@ class RompOp(C.Structure):
         ('n_terms', C.c_int32),
         ('term_buf', C.c_int32 * 4), ('term_shift', C.c_int32 * 4), ('term_cstride', C.c_int32 * 4),
         ('stream', C.c_int32), ('reserved', C.c_int32),
-        ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+        ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('weight_aux', C.c_void_p),
     ]
 
 

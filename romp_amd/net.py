@@ -15,7 +15,7 @@ from .plan import Program, build_romp_hrnet32, coord_channels
 
 class RompNet:
     def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
-                 out_shapes=None):
+                 out_shapes=None, bf16x3=False):
         """`builder(state_dict, device, input_size) -> Program` (default: ROMP HRNet-32 + head);
         `out_shapes`: per-image shapes of the two output tensors of the program."""
         self.device = torch.device(device)
@@ -25,7 +25,10 @@ class RompNet:
         self.max_batch = int(max_batch)
         self.input_size = input_size
         with torch.cuda.device(self.device):
-            self.program: Program = (builder or build_romp_hrnet32)(state_dict, self.device, input_size)
+            if builder is None:
+                self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size, bf16x3=bf16x3)
+            else:
+                self.program = builder(state_dict, self.device, input_size)
             ops = self.program.op_array()
             sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
             h = C.c_void_p()

@@ -77,6 +77,23 @@ def pack_conv_weight(w, cin_pad, cout_pad):
     return full.reshape(kh * kw, cin_pad // 4, 4, cout_pad).permute(0, 1, 3, 2).contiguous()
 
 
+def pack_conv_weight_bx3(w, cin_pad, cout_pad):
+    """Weights split into three bf16 pieces (w = w1 + w2 + w3 exactly, round-to-nearest-even like the
+    device-side activation split) for the bf16x3 conv kernels:
+    -> int16 tensor [tap][cin_pad/16][piece 3][kg 2][cout_pad][8]."""
+    if w.dim() == 3:
+        w = w.unsqueeze(2)
+    cout, cin, kh, kw = w.shape
+    full = torch.zeros(kh * kw, cin_pad, cout_pad, dtype=torch.float32)
+    full[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    p1 = full.bfloat16()
+    r1 = full - p1.float()
+    p2 = r1.bfloat16()
+    p3 = (r1 - p2.float()).bfloat16()
+    t = torch.stack([p1, p2, p3]).reshape(3, kh * kw, cin_pad // 16, 2, 8, cout_pad)
+    return t.permute(1, 2, 0, 3, 5, 4).contiguous().view(torch.int16)
+
+
 class Program:
     """The lowered network: ops (ctypes), packed constants (kept alive here), buffer sizes."""
 
@@ -93,6 +110,7 @@ class Program:
         self.cur_stream = 0
         self.in_parallel = False
         self.parallel = True                                   # emit FORK/JOIN (False: one stream)
+        self.bf16x3 = False                                    # also pack bf16x3-split weights (conv_bx3 kernels)
         self.persistent = set()
         self.head_in_buf: Optional[int] = None
 
@@ -171,6 +189,9 @@ class Program:
         for g in range(groups):
             ps[g, :cout], pb[g, :cout] = scale[g], shift[g]
         pw, ps, pb = self._dev(pw), self._dev(ps), self._dev(pb)
+        paux = None
+        if self.bf16x3 and cin_pad % 16 == 0:
+            paux = self._dev(torch.stack([pack_conv_weight_bx3(wi, cin_pad, cout_pad) for wi in w]))
         kh, kw = (1, 3) if ksize == 13 else (ksize, ksize)
         Ho = (x.H + 2 * (kh // 2) - kh) // stride + 1
         Wo = (x.W + 2 * (kw // 2) - kw) // stride + 1
@@ -190,6 +211,8 @@ class Program:
             op.res_cstride, op.res_coff, op.res_gstride = res.cstride, res.coff, (cout if groups > 1 else 0)
         op.cin_pad, op.cout_pad = cin_pad, cout_pad
         op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+        if paux is not None:
+            op.weight_aux = paux.data_ptr()
         op.stream = self.cur_stream
         self.ops.append(op)
         self.names.append(name)
@@ -354,10 +377,11 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
     return head_in
 
 
-def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512) -> Program:
+def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512, bf16x3=False) -> Program:
     """state_dict of ROMPv1 (model.py:420-481) -> Program."""
     sd = _clean(sd)
     P = Program(device)
+    P.bf16x3 = bool(bf16x3)
     # backbone output lands in 32 of the 40 channels of the head input buffer; channels 32,33 hold the
     # constant CoordConv maps (model.py:473), 34..39 are zero padding.
     build_hrnet32_backbone(P, sd, input_size, out_cstride=HEAD_IN_CH)

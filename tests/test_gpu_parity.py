@@ -190,6 +190,7 @@ def test_conv_layer(dev, case, B):
         ref = torch.relu(ref)
     ref = ref.permute(0, 2, 3, 1)
     P = Program(dev)
+    P.bf16x3 = True                      # pack the split weights too: bf16x3 variants join the sweep below
     xa = Act(0, cin, H, H, cin)
     P.buf_floats.append(cin * H * H)
     ra = None
