@@ -49,6 +49,8 @@ def bev_settings(input_args=sys.argv[1:]):
     p.add_argument('--model_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'BEV.pth'))
     p.add_argument('-t', '--temporal_optimize', action='store_true')
     p.add_argument('--max_batch', type=int, default=32)
+    p.add_argument('--conv_math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
+                   help='[romp_amd] f32 MFMA only, or also the f32-accurate bf16x3-split kernels (chosen by autotune)')
     args = p.parse_args(input_args)
     if not torch.cuda.is_available():
         args.GPU = -1
@@ -86,10 +88,10 @@ class CenterMap3D(object):
 class BEVv1(object):
     """Device-side BEVv1 (bev/model.py:104-250): network program + parse + per-person regression."""
 
-    def __init__(self, state_dict, device, center_thresh=0.1, max_batch=32):
+    def __init__(self, state_dict, device, center_thresh=0.1, max_batch=32, bf16x3=False):
         self.device = torch.device(device)
         self.net = RompNet(state_dict, self.device, max_batch=max_batch, builder=build_bev_hrnet32,
-                           out_shapes=((DEPTH, MAP, MAP), (3, DEPTH, MAP, MAP)))
+                           out_shapes=((DEPTH, MAP, MAP), (3, DEPTH, MAP, MAP)), bf16x3=bf16x3)
         self.centermap_parser = CenterMap3D(center_thresh)
         f = lambda k: state_dict[k].detach().float()
         dv = lambda t: t.contiguous().to(self.device)
@@ -172,7 +174,8 @@ class BEV(nn.Module):
         if state_dict is None:
             state_dict = torch.load(settings.model_path, map_location='cpu')
         self.model = BEVv1(state_dict, self.tdevice, center_thresh=settings.center_thresh,
-                           max_batch=getattr(settings, 'max_batch', 32))
+                           max_batch=getattr(settings, 'max_batch', 32),
+                           bf16x3=getattr(settings, 'conv_math', 'bf16x3') == 'bf16x3')
         if settings.calc_smpl:
             self.smpl_parser = SMPLA_parser(smpla_model if smpla_model is not None else settings.smpl_path,
                                             smil_model if smil_model is not None else settings.smil_path).to(self.tdevice)

@@ -39,10 +39,11 @@ def _host_floats(P: Program, values):
     return C.cast(arr, C.c_void_p).value
 
 
-def build_bev_hrnet32(sd, device, input_size=512) -> Program:
+def build_bev_hrnet32(sd, device, input_size=512, bf16x3=False) -> Program:
     assert input_size == 512, 'the BEV head is defined on a 128x128 map (bev/model.py:117)'
     sd = _clean(sd)
     P = Program(device)
+    P.bf16x3 = bool(bf16x3)
     x = build_hrnet32_backbone(P, sd, input_size, out_cstride=32)          # (B,128,128,32)
 
     def bn(name, c, bias=None):

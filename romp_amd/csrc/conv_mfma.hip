@@ -734,13 +734,13 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
         Item tgt = last ? nxt : cur;
         const int c0 = last ? 0 : (ch + 1) * CK;
         if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
-        if (pf) issue_loads(tgt, c0);
-        mma_stage_bx3<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
+        if (pf && !(p.dbg & 1)) issue_loads(tgt, c0);
+        if (!(p.dbg & 8)) mma_stage_bx3<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
         if (ch == 0 && tid == 0) sQ[0] = j_after;
         __syncthreads();
-        if (pf) write_lds(last, slot ^ 1);
+        if (pf && !(p.dbg & 2)) write_lds(last, slot ^ 1);
         if (last) {
-            conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -50,8 +50,9 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--root_align', type=bool, default=False, help='Please set this config as True to use the ROMP checkpoints trained by yourself.')
     parser.add_argument('--webcam_id', type=int, default=0, help='The Webcam ID.')
     parser.add_argument('--max_batch', type=int, default=32, help='[romp_amd] largest batch forward_batch will be called with')
-    parser.add_argument('--conv_math', type=str, default='f32', choices=['f32', 'bf16x3'],
-                        help='[romp_amd] f32: exact f32 MFMA; bf16x3: f32-accurate 3-way bf16 split on the bf16 matrix pipe (needs autotune)')
+    parser.add_argument('--conv_math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
+                        help='[romp_amd] f32: f32 MFMA kernels only; bf16x3 (default): also the f32-accurate 3-way bf16 split kernels on the '
+                             'bf16 matrix pipe, chosen per layer by measurement the first time a batch size is seen')
     parser.add_argument('--host_preprocess', action='store_true', help='[romp_amd] pad/resize on the host (cv2 / numpy) instead of the device kernel')
     args = parser.parse_args(input_args)
     if not torch.cuda.is_available():
@@ -91,7 +92,7 @@ class ROMP(nn.Module):
         if state_dict is None:
             state_dict = torch.load(self.settings.model_path, map_location='cpu')
         self.model = RompNet(state_dict, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32),
-                             bf16x3=getattr(self.settings, 'conv_math', 'f32') == 'bf16x3')
+                             bf16x3=getattr(self.settings, 'conv_math', 'bf16x3') == 'bf16x3')
 
     def _initilization_(self, smpl_model=None):
         self.centermap_parser = CenterMap(conf_thresh=self.settings.center_thresh)

@@ -16,19 +16,21 @@ from .plan import Program, build_romp_hrnet32, coord_channels
 class RompNet:
     def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
                  out_shapes=None, bf16x3=False):
-        """`builder(state_dict, device, input_size) -> Program` (default: ROMP HRNet-32 + head);
+        """`builder(state_dict, device, input_size, bf16x3=) -> Program` (default: ROMP HRNet-32 + head);
         `out_shapes`: per-image shapes of the two output tensors of the program."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
         self.lib = L.load()
         self.max_batch = int(max_batch)
+        self.bf16x3 = bool(bf16x3)
+        self._tuned = set()
         self.input_size = input_size
         with torch.cuda.device(self.device):
             if builder is None:
                 self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size, bf16x3=bf16x3)
             else:
-                self.program = builder(state_dict, self.device, input_size)
+                self.program = builder(state_dict, self.device, input_size, bf16x3=bf16x3)
             ops = self.program.op_array()
             sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
             h = C.c_void_p()
@@ -64,6 +66,8 @@ class RompNet:
         assert image.dtype == torch.float32 and image.is_cuda and image.dim() == 4 and image.shape[-1] == 3
         image = image.contiguous()
         B = image.shape[0]
+        if self.bf16x3 and B not in self._tuned:      # the bf16x3 kernels are only ever picked by measurement
+            self.autotune(B)
         if center_out is None:
             center_out = torch.empty((B,) + tuple(self.out_shapes[0]), device=self.device, dtype=torch.float32)
         if params_out is None:
@@ -81,6 +85,7 @@ class RompNet:
         """Pick the fastest conv kernel variant per layer for batch size B (measured on device)."""
         with torch.cuda.device(self.device):
             L.check(self.lib.romp_net_autotune(self._h, int(B), int(iters), L.stream_ptr(self.device)))
+        self._tuned.add(int(B))
 
     def variant_names(self, B):
         """Kernel variant name per op (tuned choice if autotune(B) ran, else the heuristic)."""

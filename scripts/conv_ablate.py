@@ -17,6 +17,7 @@ def run_case(case, B, variants, dbg):
     Ho = H // s
     res = torch.randn(B, Ho, Ho, cout, generator=g).to(dev) if use_res else None
     P = Program(dev)
+    P.bf16x3 = True
     P.buf_floats += [cin * H * H, cout * Ho * Ho]
     P.conv('t', Act(0, cin, H, H, cin), [w], [torch.ones(cout)], [torch.zeros(cout)], k, s, True,
            res=Act(1, cout, Ho, Ho, cout) if use_res else None)
@@ -50,8 +51,9 @@ if __name__ == '__main__':
         for name, us, tf in run_case(case, 32, variants, int(os.environ.get('ROMP_CONV_DEBUG', '0'))):
             print('  dbg=%-3s %-36s %8.1f us %7.1f TF' % (os.environ.get('ROMP_CONV_DEBUG', '0'), name, us, tf))
         sys.exit(0)
-    cases = [((64, 64, 3, 1, 64, True), ['mfma_k3s1_mt2_nt2_tw16', 'mfma_k3s1_mt2_nt1_tw16', 'mfma_k3s1_mt1_nt2_tw16']),
-             ((32, 32, 3, 1, 128, True), ['mfma_k3s1_mt2_nt1_tw16', 'mfma_k3s1_mt2_nt1_tw32', 'mfma_k3s1_mt1_nt1_tw32'])]
+    kind = os.environ.get('ABLATE_KIND', 'mfma')
+    cases = [((64, 64, 3, 1, 64, True), [kind + '_k3s1_mt2_nt2_tw16', kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt1_nt2_tw16']),
+             ((32, 32, 3, 1, 128, True), [kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt2_nt1_tw32', kind + '_k3s1_mt1_nt1_tw32'])]
     for case, variants in cases:
         print('case', case)
         for dbg in (0, 4, 1, 2, 3, 7, 16, 23, 8, 12):

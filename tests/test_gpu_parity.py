@@ -276,6 +276,34 @@ def test_net_vs_oracle_batch(dev, net0):
     assert torch.equal(c1.unsqueeze(1), cm) and torch.equal(c2, c1)
 
 
+def test_net_bf16x3_parity(dev, golden_dir):
+    """conv_math='bf16x3': every conv the autotuner moves onto the bf16 matrix pipe (3-way split of both
+    operands, six piece products, f32 accumulation) must pass the SAME gates as the f32-MFMA network:
+    1e-4 max-abs against the reference fixture and against the oracle."""
+    from romp_amd.net import RompNet
+    sd = O.make_romp_state_dict(0)
+    net = RompNet(sd, dev, max_batch=4, bf16x3=True)
+    net.autotune(3, iters=1)
+    names = net.variant_names(3)
+    n_bx3 = sum('bx3' in n for n in names)
+    print('convs on the bf16x3 kernels at B=3: %d of %d ops' % (n_bx3, len(names)))
+    assert n_bx3 > 0
+    img = O.make_images(3, seed=5)
+    cm_o, pm_o = O.romp_net_forward(sd, img)
+    cm, pm = net(img.to(dev))
+    ec, ep = (cm.cpu() - cm_o).abs().max().item(), (pm.cpu() - pm_o).abs().max().item()
+    print(f'bf16x3 B=3 vs oracle: center {ec:.3e} params {ep:.3e}')
+    assert ec < 1e-4 and ep < 1e-4
+    g = _g(golden_dir, 'romp_net_b1.npz')
+    net.autotune(1, iters=1)
+    cm, pm = net(O.make_images(1, seed=1).to(dev))
+    p = pm[0].reshape(145, -1).cpu().numpy()
+    ec = np.abs(cm.cpu().numpy() - g['center_maps']).max()
+    ep = np.abs(p[:, g['sample_pos']] - g['params_samples']).max()
+    print(f'bf16x3 B=1 vs reference fixture: center {ec:.3e} params {ep:.3e}')
+    assert ec < 1e-4 and ep < 1e-4
+
+
 def test_net_full_batch_properties(dev):
     """BASELINE config 2 size (B=32): images repeated inside the batch must give identical maps
     (no cross-image leakage, tile/batch indexing correct at full size), and a permuted batch must
