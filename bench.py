@@ -49,6 +49,8 @@ def parse_args():
                     help='f32: exact f32 MFMA kernels only; bf16x3: also offer the f32-accurate bf16x3-split kernels to the autotuner')
     ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
+    ap.add_argument('--tune-file', type=str, default=None,
+                    help='JSON cache of the autotuned variant table: loaded if it exists (no measuring launches), else written')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-roofline', action='store_true')
@@ -209,8 +211,12 @@ def main():
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
     model.model.set_streams(args.streams)
-    if args.autotune:
+    if args.tune_file and os.path.exists(args.tune_file):
+        model.model.set_tuned(args.batch, json.load(open(args.tune_file))[str(args.batch)])
+    elif args.autotune:
         model.model.autotune(args.batch)
+        if args.tune_file and rank == 0:
+            json.dump({str(args.batch): model.model.tuned_variants(args.batch)}, open(args.tune_file, 'w'))
     if args.graph:
         model.model.set_graph(True)
     B = args.batch

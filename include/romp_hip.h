@@ -116,6 +116,9 @@ int  romp_net_set_graph(romp_net* net, int enable);
 int  romp_net_autotune(romp_net* net, int B, int iters, void* stream);
 /* Variant index chosen by romp_net_autotune for op `op_index` at batch B (-1: heuristic). */
 int  romp_net_tuned_variant(romp_net* net, int B, int op_index);
+/* Install a variant table for batch B without measuring (e.g. one saved from an earlier autotune):
+ * variants[n_ops], -1 = heuristic.  An index that is not valid for its op is ROMP_EINVAL. */
+int  romp_net_set_tuned(romp_net* net, int B, const int32_t* variants, int n_ops);
 /* Time the most recent forward per op (HIP events on `stream`); ms_out_host[n_ops]. */
 int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,
                       float* params_maps_nhwc, void* stream, float* ms_out_host, int iters);

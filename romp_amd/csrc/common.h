@@ -34,6 +34,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
                 int mode, int variant, int* queue, hipStream_t st);
 int describe_conv(const romp_op& op, int B, int variant, char* out, int n);
 int conv_num_variants();
+int conv_init();
 bool conv_variant_valid(const romp_op& op, int variant);
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
 struct FuseTerm { const float* ptr; int shift; int cstride; };

@@ -763,6 +763,234 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16x3, second generation ("bxd"): same arithmetic as conv_bx3_kernel, different data movement.
+// Measured on conv_bx3 (64->64 @64x64, B=32): LDS traffic (fragment reads + staging writes) ran at
+// ~95 % of the LDS peak at the MFMA rate the kernel was aiming for, and the re-fetch of the pre-split
+// weight slab by every 128-pixel workgroup tile drew ~10 TB/s from L2.  Here:
+//   * the weight slab is staged one TAP ROW (KW taps) at a time, by LDS-DMA (global_load_lds_dwordx4:
+//     no staging VGPRs, no ds_write pass), double-buffered: the DMA of sub-stage n+1 runs under the
+//     MFMAs of sub-stage n and is retired (vmcnt(0)) before the barrier that ends sub-stage n;
+//   * the 56 VGPRs the weight staging used are gone, so a wave can own a 2x2 block tile (64 pixels x
+//     64 channels) at TWO workgroups per CU without spilling: 12 fragment reads per 24 MFMAs instead
+//     of 9 per 12, and each weight byte fetched from L2 feeds twice the pixels;
+//   * activations are still staged through registers (they must be split into bf16 pieces on the way).
+// LDS per workgroup (MT=NT=2, TW=16, CK=16): 36.3 KB pixels + 2 x 18.4 KB weight rows = 74 KB.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int KS, int S, int MT, int NT, int TW, int CK>
+struct BdCfg {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    static constexpr int K16 = CK / 16;
+    static constexpr int PSB = 3 * CK * 2 + 16;
+    static constexpr int A_BYTES = C::HR * C::HC * PSB;
+    static constexpr int SUB_UNITS = C::KW * 3 * K16 * 2 * C::NW;      // 16-byte units of one tap row: [dx][piece][k16][kg][NW]
+    static constexpr int NBD = (SUB_UNITS + 255) / 256;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * SUB_UNITS * 16 + 4 * C::NW * 4 + 32;
+    static_assert(SUB_UNITS % 64 == 0, "a wave's LDS-DMA writes 64 consecutive units");
+};
+
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    using X = BdCfg<KS, S, MT, NT, TW, CK>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sA = reinterpret_cast<char*>(smem);
+    char* sB = sA + X::A_BYTES;                                   // two tap-row buffers
+    float* sS = reinterpret_cast<float*>(sB + 2 * X::SUB_UNITS * 16);
+    int* sQ = reinterpret_cast<int*>(sS + 4 * C::NW);             // [0..1] first two items, [2..3] item-ahead mailbox
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
+    const int n_chunks = p.cin_pad / CK;
+    const int cin16 = p.cin_pad >> 4;
+
+    if (tid == 0) {
+        sQ[0] = atomicAdd(p.queue + q, 1);
+        sQ[1] = atomicAdd(p.queue + q, 1);
+    }
+    __syncthreads();
+    int j_cur = sQ[0], j_next = sQ[1];
+    if (j_cur >= p.per_queue) return;
+
+    float4 ra[C::NA];
+    float rs = 0.f;
+
+    // LDS-DMA of the weight units of tap row `row`, channel chunk c0, into buffer `buf`
+    auto issue_B = [&](const Item& it, int c0, int row, int buf) {
+        const uint4* wg = p.w3 + (size_t)it.g * (C::TAPS * cin16 * 6 * p.cout_pad);
+        char* dst = sB + buf * (X::SUB_UNITS * 16);
+#pragma unroll
+        for (int k = 0; k < X::NBD; ++k) {
+            if (k * 256 + wave * 64 < X::SUB_UNITS) {             // wave-uniform
+                int r = k * 256 + tid;
+                const int j = r % C::NW; r /= C::NW;
+                const int kg = r & 1; r >>= 1;
+                const int k16 = r % X::K16; r /= X::K16;
+                const int pc = r % 3;
+                const int dx = r / 3;
+                const int tap = row * C::KW + dx;
+                const uint4* src = wg + (unsigned)(((((tap * cin16 + (c0 >> 4) + k16) * 3 + pc) * 2 + kg) * p.cout_pad) + it.n0 + j);
+                __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(dst + (k * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_A = [&](const Item& it, int c0) {
+        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
+        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
+#pragma unroll
+        for (int k = 0; k < C::NA; ++k) {
+            const int idx = tid + k * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < C::A_VEC) {
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                const int hx = pix % C::HC, hy = pix / C::HC;
+                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
+                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
+            }
+            ra[k] = v;
+        }
+        if (c0 == 0 && tid < 2 * C::NW) {
+            const float* src = tid < C::NW ? p.scale : p.shift;
+            rs = src[it.g * p.cout_pad + it.n0 + (tid & (C::NW - 1))];
+        }
+    };
+    auto write_A = [&](bool first_chunk, int slot) {
+#pragma unroll
+        for (int k = 0; k < C::NA; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < C::A_VEC) {
+                const int qq = idx % C::QC, pix = idx / C::QC;
+                unsigned short h[4][3];
+                split3(ra[k].x, h[0][0], h[0][1], h[0][2]);
+                split3(ra[k].y, h[1][0], h[1][1], h[1][2]);
+                split3(ra[k].z, h[2][0], h[2][1], h[2][2]);
+                split3(ra[k].w, h[3][0], h[3][1], h[3][2]);
+                char* dst = sA + pix * X::PSB + qq * 8;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    uint2 u;
+                    u.x = (unsigned)h[0][pc] | ((unsigned)h[1][pc] << 16);
+                    u.y = (unsigned)h[2][pc] | ((unsigned)h[3][pc] << 16);
+                    *reinterpret_cast<uint2*>(dst + pc * (CK * 2)) = u;
+                }
+            }
+        }
+        if (first_chunk && tid < 2 * C::NW) sS[slot * 2 * C::NW + tid] = rs;
+    };
+
+    int xoff[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mb = wave * MT + m;
+        const int row = mb * C::RPB + li / TW, col = li % TW;
+        xoff[m] = ((row * S) * C::HC + col * S) * X::PSB + lh * 16;
+    }
+    const int woff = (lh * C::NW + li) * 16;
+
+    Item cur = decode_item(p, q, j_cur, C::NW);
+    issue_B(cur, 0, 0, 0);
+    issue_A(cur, 0);
+    write_A(true, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int slot = 0, ch = 0, row = 0, bbuf = 0, par = 0;
+    Item nxt = cur;
+    bool have_next = j_next < p.per_queue;
+    if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+    int j_after = 0x7fffffff;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+#pragma unroll 1
+    while (true) {
+        const bool last_row = row + 1 == C::KH;
+        const bool last_ch = ch + 1 == n_chunks;
+        const bool last = last_row && last_ch;                    // last sub-stage of the item
+        // what the NEXT sub-stage needs
+        const bool pfB = !last || have_next;
+        const Item tgtB = last ? nxt : cur;
+        const int c0B = last_row ? (last_ch ? 0 : (ch + 1) * CK) : ch * CK;
+        const int rowB = last_row ? 0 : row + 1;
+        if (ch == 0 && row == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
+        if (pfB && !(p.dbg & 1)) issue_B(tgtB, c0B, rowB, bbuf ^ 1);
+        const bool pfA = last_row && pfB;                          // next chunk's pixels: loaded under the last tap row
+        if (pfA && !(p.dbg & 1)) issue_A(tgtB, c0B);
+        if (!(p.dbg & 8)) {
+            const char* sBc = sB + bbuf * (X::SUB_UNITS * 16);
+#pragma unroll
+            for (int dx = 0; dx < C::KW; ++dx)
+#pragma unroll
+                for (int k16 = 0; k16 < X::K16; ++k16) {
+                    bf16x8 xf[MT][3], wf[NT][3];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            xf[m][pc] = *reinterpret_cast<const bf16x8*>(sA + xoff[m] + (row * C::HC + dx) * X::PSB + pc * (CK * 2) + k16 * 32);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            wf[n][pc] = *reinterpret_cast<const bf16x8*>(sBc + woff + ((((dx * 3 + pc) * X::K16 + k16) * 2) * C::NW + n * 32) * 16);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {            // smallest terms first
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][2], xf[m][0], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][1], xf[m][1], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], xf[m][2], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][1], xf[m][0], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], xf[m][1], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[n][0], xf[m][0], acc[m][n], 0, 0, 0);
+                        }
+                }
+        }
+        if (ch == 0 && row == 0 && tid == 0) sQ[2 + par] = j_after;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA has landed (and ra is in)
+        __syncthreads();                                           // all waves: done reading bbuf / sA, DMA visible
+        bbuf ^= 1;
+        if (last_row) {
+            if (pfA && !(p.dbg & 2)) write_A(last_ch, slot ^ 1);
+            if (last_ch) {
+                if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+                if (!have_next) break;
+            }
+            __syncthreads();                                       // next chunk's pixels visible
+            row = 0;
+            if (last_ch) {
+                cur = nxt;
+                slot ^= 1;
+                ch = 0;
+                j_next = sQ[2 + par];
+                par ^= 1;
+                have_next = j_next < p.per_queue;
+                if (have_next) nxt = decode_item(p, q, j_next, C::NW);
+            } else {
+                ++ch;
+            }
+        } else {
+            ++row;
+        }
+    }
+}
+
 // Bring-up cross-check: one thread per output element, same packed weights, plain FMA loop.
 __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups) {
     const size_t total = (size_t)B * p.Ho * p.Wo * p.Cout * groups;
@@ -804,6 +1032,9 @@ struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int
 #define ROMP_CONV_VARIANT_PP(KS, S, MT, NT, TW, CK)                                   \
     { KS, S, MT, NT, TW, CK, conv_pp_kernel<KS, S, MT, NT, TW, CK>,                   \
       2 * ConvCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 1, 0 }
+#define ROMP_CONV_VARIANT_BXD(KS, S, MT, NT, TW, CK)                                  \
+    { KS, S, MT, NT, TW, CK, conv_bxd_kernel<KS, S, MT, NT, TW, CK>,                  \
+      BdCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 2 }
 #define ROMP_CONV_VARIANT_BX3(KS, S, MT, NT, TW, CK)                                  \
     { KS, S, MT, NT, TW, CK, conv_bx3_kernel<KS, S, MT, NT, TW, CK>,                  \
       BxCfg<KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 1 }
@@ -838,6 +1069,10 @@ static ConvVariant kVariants[] = {
     ROMP_CONV_VARIANT_BX3(3, 2, 1, 2, 16, 16), ROMP_CONV_VARIANT_BX3(3, 2, 1, 1, 16, 16), ROMP_CONV_VARIANT_BX3(3, 2, 1, 2, 32, 16),
     ROMP_CONV_VARIANT_BX3(1, 1, 2, 2, 32, 32), ROMP_CONV_VARIANT_BX3(1, 1, 2, 1, 32, 32), ROMP_CONV_VARIANT_BX3(1, 1, 1, 2, 16, 32),
     ROMP_CONV_VARIANT_BX3(1, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_BX3(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_BX3(13, 1, 2, 2, 32, 16),
+    // bf16x3 with LDS-DMA weight rows
+    ROMP_CONV_VARIANT_BXD(3, 1, 2, 2, 16, 16), ROMP_CONV_VARIANT_BXD(3, 1, 2, 2, 32, 16),
+    ROMP_CONV_VARIANT_BXD(3, 1, 2, 1, 16, 16), ROMP_CONV_VARIANT_BXD(3, 1, 2, 1, 32, 16),
+    ROMP_CONV_VARIANT_BXD(3, 1, 1, 2, 16, 16), ROMP_CONV_VARIANT_BXD(3, 1, 4, 1, 32, 16),
     // ping-pong (8 waves, two alternating groups)
     ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 2, 1, 16, 16),
     ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_PP(3, 1, 1, 2, 16, 16),
@@ -877,9 +1112,13 @@ static int ensure_attrs() {
     return ROMP_OK;
 }
 
+// One-time per-process setup (LDS attributes, occupancy, scratch queue).  romp_net_create calls it so
+// that it never runs inside a stream capture (hipMalloc / hipFuncSetAttribute are illegal there).
+int conv_init() { return ensure_attrs(); }
+
 static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) {
     if (v.lds > kMaxLds) return false;
-    if (v.math == 1 && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
+    if (v.math && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.ks != op.ksize || v.s != op.stride) return false;
     if (Wo % v.tw) return false;                     // rows may be partial (masked), columns may not
     if (op.cin_pad % v.ck || op.cout_pad % (v.nt * 32)) return false;
@@ -984,7 +1223,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }

@@ -179,6 +179,7 @@ const char* romp_last_error(void) { return romp::g_err; }
 int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const int64_t* buf_floats, int n_bufs,
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
+    { const int rc = conv_init(); if (rc) return rc; }
     romp_net* n = new romp_net();
     n->ops.assign(ops_host, ops_host + n_ops);
     n->buf_floats.assign(buf_floats, buf_floats + n_bufs);
@@ -396,6 +397,20 @@ int romp_net_tuned_variant(romp_net* n, int B, int op_index) {
     if (!n || op_index < 0 || op_index >= (int)n->ops.size()) return -1;
     const std::vector<int>* tv = tuned_for(n, B);
     return tv ? (*tv)[op_index] : -1;
+}
+
+int romp_net_set_tuned(romp_net* n, int B, const int32_t* variants, int n_ops) {
+    ROMP_REQUIRE(n && variants && B > 0 && n_ops == (int)n->ops.size(), "romp_net_set_tuned: bad arguments");
+    std::vector<int> tv(n_ops, -1);
+    for (int i = 0; i < n_ops; ++i) {
+        if (variants[i] < 0 || n->ops[i].kind != ROMP_OP_CONV) continue;
+        ROMP_REQUIRE(conv_variant_valid(n->ops[i], variants[i]), "romp_net_set_tuned: variant %d is not valid for op %d", variants[i], i);
+        tv[i] = variants[i];
+    }
+    n->tuned[B] = tv;
+    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
+    n->graphs.clear();
+    return ROMP_OK;
 }
 
 }  // extern "C"

@@ -87,6 +87,16 @@ class RompNet:
             L.check(self.lib.romp_net_autotune(self._h, int(B), int(iters), L.stream_ptr(self.device)))
         self._tuned.add(int(B))
 
+    def tuned_variants(self, B):
+        """Variant index per op for batch B (-1 = heuristic): what autotune(B) chose."""
+        return [self.lib.romp_net_tuned_variant(self._h, int(B), i) for i in range(len(self.program.ops))]
+
+    def set_tuned(self, B, variants):
+        """Install a saved variant table (from tuned_variants) instead of measuring."""
+        arr = (C.c_int32 * len(variants))(*[int(v) for v in variants])
+        L.check(self.lib.romp_net_set_tuned(self._h, int(B), arr, len(variants)))
+        self._tuned.add(int(B))
+
     def variant_names(self, B):
         """Kernel variant name per op (tuned choice if autotune(B) ran, else the heuristic)."""
         buf = C.create_string_buffer(128)

@@ -48,7 +48,7 @@ def run_case(case, B, variants, dbg):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'child':
         case = tuple(json.loads(sys.argv[2])); variants = json.loads(sys.argv[3])
-        for name, us, tf in run_case(case, 32, variants, int(os.environ.get('ROMP_CONV_DEBUG', '0'))):
+        for name, us, tf in run_case(case, int(os.environ.get('ABLATE_B', '32')), variants, int(os.environ.get('ROMP_CONV_DEBUG', '0'))):
             print('  dbg=%-3s %-36s %8.1f us %7.1f TF' % (os.environ.get('ROMP_CONV_DEBUG', '0'), name, us, tf))
         sys.exit(0)
     kind = os.environ.get('ABLATE_KIND', 'mfma')
@@ -56,7 +56,7 @@ if __name__ == '__main__':
              ((32, 32, 3, 1, 128, True), [kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt2_nt1_tw32', kind + '_k3s1_mt1_nt1_tw32'])]
     for case, variants in cases:
         print('case', case)
-        for dbg in (0, 4, 1, 2, 3, 7, 16, 23, 8, 12):
+        for dbg in [int(x) for x in os.environ.get('ABLATE_DBG', '0,4,1,2,3,7,16,23,8,12').split(',')]:
             env = dict(os.environ, ROMP_CONV_DEBUG=str(dbg))
             r = subprocess.run([sys.executable, __file__, 'child', json.dumps(case), json.dumps(variants)], env=env,
                                capture_output=True, text=True)

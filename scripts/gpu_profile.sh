@@ -6,7 +6,13 @@ OUT="$REPO/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export PYTHONUNBUFFERED=1
-BENCH="python $REPO/bench.py --no-cpu-baseline"
+# tune once OUTSIDE the profiler and reuse the table, so the traces hold the forward's kernels only
+# (no autotune measuring launches); ${BENCH_ARGS} e.g. "--conv-math f32" or "--workload bev"
+TUNE=/tmp/romp_tune.json
+rm -f $TUNE
+BENCH="python $REPO/bench.py --no-cpu-baseline --tune-file $TUNE ${BENCH_ARGS}"
+$BENCH --steps 2 --warmup 1 --no-roofline > "$OUT/bench_plain.log" 2>&1
+echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
 echo "stats pass exit $?"
 find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
