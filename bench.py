@@ -49,6 +49,8 @@ def parse_args():
                     help='f32: exact f32 MFMA kernels only; bf16x3: also offer the f32-accurate bf16x3-split kernels to the autotuner')
     ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
+    ap.add_argument('--split', type=int, default=1, help='2: run the batch as two half-batch lanes on two streams (convs capped at --wg-cap WG/CU)')
+    ap.add_argument('--wg-cap', type=int, default=1)
     ap.add_argument('--tune-file', type=str, default=None,
                     help='JSON cache of the autotuned variant table: loaded if it exists (no measuring launches), else written')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -62,6 +64,8 @@ def roofline_report(model, images, lib, L):
     """Per kernel variant: sum of algorithmic FLOPs / bytes over its launches / sum of HIP-event
     durations (events recorded on the launch stream around every layer kernel)."""
     net = model.model
+    if net.split == 2:                       # batch lanes: the kernels run on half batches
+        images = images[:images.shape[0] // 2].contiguous()
     B = images.shape[0]
     ms = net.profile(images, iters=3)
     agg = {}
@@ -211,12 +215,15 @@ def main():
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
     model.model.set_streams(args.streams)
+    if args.split == 2:
+        model.model.set_split(2, args.wg_cap)
+    Bt = args.batch // 2 if args.split == 2 else args.batch          # batch the kernels see
     if args.tune_file and os.path.exists(args.tune_file):
-        model.model.set_tuned(args.batch, json.load(open(args.tune_file))[str(args.batch)])
+        model.model.set_tuned(Bt, json.load(open(args.tune_file))[str(Bt)])
     elif args.autotune:
-        model.model.autotune(args.batch)
+        model.model.autotune(Bt)
         if args.tune_file and rank == 0:
-            json.dump({str(args.batch): model.model.tuned_variants(args.batch)}, open(args.tune_file, 'w'))
+            json.dump({str(Bt): model.model.tuned_variants(Bt)}, open(args.tune_file, 'w'))
     if args.graph:
         model.model.set_graph(True)
     B = args.batch
@@ -264,7 +271,7 @@ def main():
         'config': {'workload': 'ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); '
                                'net+parse+SMPL%s' % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'persons_per_image': round(persons / (B * world), 2),
-                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math, 'parallelism': 'dp%d' % world},
+                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math, 'batch_lanes': args.split, 'parallelism': 'dp%d' % world},
     }
     if rank == 0:
         if not args.no_roofline:

@@ -114,6 +114,13 @@ int  romp_net_set_graph(romp_net* net, int enable);
 /* Measure every valid kernel variant of every conv layer at batch B (HIP events on `stream`,
  * `iters` timed runs each) and use the fastest from now on for that batch size. */
 int  romp_net_autotune(romp_net* net, int B, int iters, void* stream);
+/* Batch lanes: lanes == 2 runs a forward of an even batch B as two independent half-batch sequences on
+ * two HIP streams (lane 0 on the caller's stream; each with its own branch side streams), every conv
+ * limited to `wg_cap` workgroups per CU (0: no limit) so that kernels of the two lanes share each CU
+ * in different phases.  Kernel variants are then looked up for batch B/2.  The per-image float counts
+ * of the caller's image / center / params tensors give the lane offsets.  lanes == 1: off. */
+int  romp_net_set_split(romp_net* net, int lanes, int wg_cap, int64_t image_floats, int64_t center_floats,
+                        int64_t params_floats);
 /* Variant index chosen by romp_net_autotune for op `op_index` at batch B (-1: heuristic). */
 int  romp_net_tuned_variant(romp_net* net, int B, int op_index);
 /* Install a variant table for batch B without measuring (e.g. one saved from an earlier autotune):

@@ -30,8 +30,9 @@ void set_error(const char* fmt, ...);
 
 // launchers implemented in the kernel translation units
 // variant < 0: heuristic choice; queue: 8 zeroed ints (nullptr: library scratch, memset on `st`)
+// wg_cap > 0: at most that many workgroups per CU (room for a co-resident kernel of another stream)
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B,
-                int mode, int variant, int* queue, hipStream_t st);
+                int mode, int variant, int* queue, hipStream_t st, int wg_cap = 0);
 int describe_conv(const romp_op& op, int B, int variant, char* out, int n);
 int conv_num_variants();
 int conv_init();

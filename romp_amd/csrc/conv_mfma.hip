@@ -1157,7 +1157,7 @@ bool conv_variant_valid(const romp_op& op, int variant) {
 }
 
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B, int mode,
-                int variant, int* queue, hipStream_t st) {
+                int variant, int* queue, hipStream_t st, int wg_cap) {
     ROMP_REQUIRE(op.ksize == 1 || op.ksize == 3 || op.ksize == 13, "conv: ksize %d unsupported", op.ksize);
     ROMP_REQUIRE(op.stride == 1 || op.stride == 2, "conv: stride %d unsupported", op.stride);
     ROMP_REQUIRE(op.groups >= 1, "conv: groups must be >= 1");
@@ -1208,7 +1208,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     }
     p.queue = queue;
     const long items = (long)p.tiles_total * p.ns_total;
-    long grid = (long)g_num_cu * v.occ;
+    long grid = (long)g_num_cu * ((wg_cap > 0 && wg_cap < v.occ) ? wg_cap : v.occ);   // wg_cap: leave room for a co-resident kernel
     const long want = v.pp ? (items + 1) / 2 : items;         // a ping-pong workgroup runs two item streams
     if (grid > want) grid = want;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;    // same number of workgroups per queue

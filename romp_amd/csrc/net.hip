@@ -27,9 +27,9 @@ void set_error(const char* fmt, ...) {
 using namespace romp;
 
 struct GraphKey {
-    int B; const void* img; void* center; void* params;
+    int B; const void* img; void* center; void* params; int lane;      // lane -1: whole forward in one graph
     bool operator<(const GraphKey& o) const {
-        return std::tie(B, img, center, params) < std::tie(o.B, o.img, o.center, o.params);
+        return std::tie(B, img, center, params, lane) < std::tie(o.B, o.img, o.center, o.params, o.lane);
     }
 };
 
@@ -37,33 +37,48 @@ struct romp_net {
     std::vector<romp_op> ops;
     std::vector<int64_t> buf_floats;     // per image
     std::vector<float*> bufs;
-    int* queues = nullptr;               // n_ops x 8 work counters, zeroed at the start of a forward
+    int* queues = nullptr;               // 2 lanes x n_ops x 8 work counters, zeroed at the start of a forward
     int max_batch = 0;
     int mode = 0;
     int use_graph = 0;
     int use_streams = 1;                 // run FORK/JOIN regions on side streams
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr;
-    hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr};
+    // Batch lanes: with split == 2 a forward of B images runs as two independent half-batch op sequences
+    // on two streams (lane 0 on the caller's stream), each conv capped at one workgroup per CU, so the
+    // two lanes' kernels co-reside on every CU in different phases: one lane's synchronized epilogue /
+    // prologue memory bursts run under the other lane's MFMA phase instead of stalling the chip.
+    int split = 1;
+    int wg_cap = 0;                      // workgroups per CU a conv may take (0: all it can)
+    int64_t image_floats = 0, center_floats = 0, params_floats = 0;   // per image, for the lane offsets
+    hipStream_t lane_main = nullptr;     // lane 1's main stream
+    hipStream_t side[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipEvent_t ev_fork[2] = {nullptr, nullptr};
+    hipEvent_t ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipEvent_t ev_begin = nullptr, ev_offset = nullptr, ev_done = nullptr;
     std::map<int, std::vector<int>> tuned;   // batch -> variant per op (-1: heuristic)
     std::map<GraphKey, hipGraphExec_t> graphs;
 };
 
-static const float* resolve_in(romp_net* n, int buf, const float* image) {
+// Arena buffers are batch-major: image b of buffer `buf` starts at b * buf_floats[buf].  `b0` is the
+// first image of the lane being run (0 unless the forward is split into batch lanes); the caller's
+// image / center / params pointers are already offset.
+static const float* resolve_in(romp_net* n, int buf, const float* image, int b0) {
     if (buf == ROMP_BUF_IMAGE) return image;
-    if (buf >= 0 && buf < (int)n->bufs.size()) return n->bufs[buf];
+    if (buf >= 0 && buf < (int)n->bufs.size()) return n->bufs[buf] + (size_t)b0 * n->buf_floats[buf];
     return nullptr;
 }
-static float* resolve_out(romp_net* n, int buf, float* center, float* params) {
+static float* resolve_out(romp_net* n, int buf, float* center, float* params, int b0) {
     if (buf == ROMP_BUF_CENTER) return center;
     if (buf == ROMP_BUF_PARAMS) return params;
-    if (buf >= 0 && buf < (int)n->bufs.size()) return n->bufs[buf];
+    if (buf >= 0 && buf < (int)n->bufs.size()) return n->bufs[buf] + (size_t)b0 * n->buf_floats[buf];
     return nullptr;
 }
 
 static int run_op(romp_net* n, size_t idx, int variant, const float* image, int B, float* center, float* params,
-                  hipStream_t st) {
+                  hipStream_t st, int lane = 0, int b0 = 0) {
     const romp_op& op = n->ops[idx];
+    int* queue = n->queues + ((size_t)lane * n->ops.size() + idx) * 8;
+    auto resolve_in = [&](romp_net* nn, int buf, const float* img) { return ::resolve_in(nn, buf, img, b0); };
+    auto resolve_out = [&](romp_net* nn, int buf, float* c, float* p) { return ::resolve_out(nn, buf, c, p, b0); };
     switch (op.kind) {
         case ROMP_OP_STEM: {
             const float* in = resolve_in(n, op.in_buf, image);
@@ -101,14 +116,14 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
                 ROMP_REQUIRE(in1 && out1 && op.res_buf == ROMP_BUF_NONE, "conv1d: bad buffers");
                 romp_op o1 = op;
                 o1.H = B;
-                return launch_conv(o1, in1, nullptr, out1, 1, n->mode, variant, n->queues + idx * 8, st);
+                return launch_conv(o1, in1, nullptr, out1, 1, n->mode, variant, queue, st, n->wg_cap);
             }
             const float* in = resolve_in(n, op.in_buf, image);
             float* out = resolve_out(n, op.out_buf, center, params);
             const float* res = op.res_buf == ROMP_BUF_NONE ? nullptr : resolve_in(n, op.res_buf, image);
             ROMP_REQUIRE(in && out, "conv: bad buffers %d -> %d", op.in_buf, op.out_buf);
             ROMP_REQUIRE(op.res_buf == ROMP_BUF_NONE || res, "conv: bad residual buffer %d", op.res_buf);
-            return launch_conv(op, in, res, out, B, n->mode, variant, n->queues + idx * 8, st);
+            return launch_conv(op, in, res, out, B, n->mode, variant, queue, st, n->wg_cap);
         }
         case ROMP_OP_FUSESUM: {
             FuseTerm t[4];
@@ -138,36 +153,66 @@ static const std::vector<int>* tuned_for(romp_net* n, int B) {
 }
 
 static int reset_queues(romp_net* n, hipStream_t st) {
-    ROMP_HIP_CHECK(hipMemsetAsync(n->queues, 0, n->ops.size() * 8 * sizeof(int), st));
+    ROMP_HIP_CHECK(hipMemsetAsync(n->queues, 0, 2 * n->ops.size() * 8 * sizeof(int), st));
     return ROMP_OK;
 }
 
-static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st) {
-    int rc = reset_queues(n, st);
-    if (rc) return rc;
+// One op sequence (a whole batch, or one batch lane) on `st` with its FORK/JOIN regions on the lane's side streams.
+static int run_lane(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st, int lane, int b0,
+                    hipEvent_t ev_after_first_convs) {
     const std::vector<int>* tv = tuned_for(n, B);
     const bool ms = n->use_streams && n->mode == 0;
+    int convs_seen = 0;
     for (size_t i = 0; i < n->ops.size(); ++i) {
         const romp_op& op = n->ops[i];
         if (op.kind == ROMP_OP_FORK) {
             if (!ms) continue;
             ROMP_REQUIRE(op.Cin >= 1 && op.Cin <= 3, "fork: %d side streams", op.Cin);
-            ROMP_HIP_CHECK(hipEventRecord(n->ev_fork, st));
-            for (int k = 0; k < op.Cin; ++k) ROMP_HIP_CHECK(hipStreamWaitEvent(n->side[k], n->ev_fork, 0));
+            ROMP_HIP_CHECK(hipEventRecord(n->ev_fork[lane], st));
+            for (int k = 0; k < op.Cin; ++k) ROMP_HIP_CHECK(hipStreamWaitEvent(n->side[lane][k], n->ev_fork[lane], 0));
             continue;
         }
         if (op.kind == ROMP_OP_JOIN) {
             if (!ms) continue;
             for (int k = 0; k < op.Cin; ++k) {
-                ROMP_HIP_CHECK(hipEventRecord(n->ev_join[k], n->side[k]));
-                ROMP_HIP_CHECK(hipStreamWaitEvent(st, n->ev_join[k], 0));
+                ROMP_HIP_CHECK(hipEventRecord(n->ev_join[lane][k], n->side[lane][k]));
+                ROMP_HIP_CHECK(hipStreamWaitEvent(st, n->ev_join[lane][k], 0));
             }
             continue;
         }
-        hipStream_t s = (ms && op.stream >= 1 && op.stream <= 3) ? n->side[op.stream - 1] : st;
-        rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, s);
+        hipStream_t s = (ms && op.stream >= 1 && op.stream <= 3) ? n->side[lane][op.stream - 1] : st;
+        const int rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, s, lane, b0);
         if (rc) return rc;
+        if (ev_after_first_convs && op.kind == ROMP_OP_CONV && ++convs_seen == 2)      // lane 1 starts ~two layers behind lane 0
+            ROMP_HIP_CHECK(hipEventRecord(ev_after_first_convs, st));
     }
+    return ROMP_OK;
+}
+
+static bool lanes_active(const romp_net* n, int B) { return n->split == 2 && n->mode == 0 && B >= 2 && !(B & 1); }
+
+static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st) {
+    int rc = reset_queues(n, st);
+    if (rc) return rc;
+    if (!lanes_active(n, B)) {
+        const int cap = n->wg_cap;
+        if (n->split == 2) n->wg_cap = 0;              // an unsplit forward (odd / single-image batch) takes the whole chip
+        rc = run_lane(n, image, B, center, params, st, 0, 0, nullptr);
+        n->wg_cap = cap;
+        return rc;
+    }
+    const int B0 = B / 2;
+    ROMP_HIP_CHECK(hipEventRecord(n->ev_begin, st));                        // after the queue reset
+    ROMP_HIP_CHECK(hipEventRecord(n->ev_offset, st));                       // (re-recorded two convs into lane 0)
+    rc = run_lane(n, image, B0, center, params, st, 0, 0, n->ev_offset);
+    if (rc) return rc;
+    ROMP_HIP_CHECK(hipStreamWaitEvent(n->lane_main, n->ev_begin, 0));
+    ROMP_HIP_CHECK(hipStreamWaitEvent(n->lane_main, n->ev_offset, 0));
+    rc = run_lane(n, image + (size_t)B0 * n->image_floats, B0, center + (size_t)B0 * n->center_floats,
+                  params + (size_t)B0 * n->params_floats, n->lane_main, 1, B0, nullptr);
+    if (rc) return rc;
+    ROMP_HIP_CHECK(hipEventRecord(n->ev_done, n->lane_main));
+    ROMP_HIP_CHECK(hipStreamWaitEvent(st, n->ev_done, 0));
     return ROMP_OK;
 }
 
@@ -197,15 +242,21 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
         e = hipMemset(n->bufs[i], 0, bytes);
         if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); romp_net_destroy(n); return ROMP_EHIP; }
     }
-    if (hipMalloc((void**)&n->queues, (size_t)n_ops * 8 * sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&n->queues, (size_t)2 * n_ops * 8 * sizeof(int)) != hipSuccess) {
         set_error("queue allocation failed");
         romp_net_destroy(n);
         return ROMP_ENOMEM;
     }
-    bool ok = hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 3 && ok; ++k)
-        ok = hipStreamCreateWithFlags(&n->side[k], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&n->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&n->lane_main, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&n->ev_begin, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&n->ev_offset, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&n->ev_done, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; l < 2 && ok; ++l) {
+        ok = hipEventCreateWithFlags(&n->ev_fork[l], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 3 && ok; ++k)
+            ok = hipStreamCreateWithFlags(&n->side[l][k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&n->ev_join[l][k], hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) {
         set_error("side stream / event creation failed");
         romp_net_destroy(n);
@@ -229,6 +280,17 @@ int romp_net_set_streams(romp_net* n, int enable) {
     return ROMP_OK;
 }
 
+int romp_net_set_split(romp_net* n, int lanes, int wg_cap, int64_t image_floats, int64_t center_floats, int64_t params_floats) {
+    ROMP_REQUIRE(n && (lanes == 1 || lanes == 2) && wg_cap >= 0, "romp_net_set_split: bad arguments");
+    ROMP_REQUIRE(lanes == 1 || (image_floats > 0 && center_floats > 0 && params_floats > 0), "romp_net_set_split: per-image sizes missing");
+    n->split = lanes;
+    n->wg_cap = wg_cap;
+    n->image_floats = image_floats; n->center_floats = center_floats; n->params_floats = params_floats;
+    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
+    n->graphs.clear();
+    return ROMP_OK;
+}
+
 int romp_net_set_graph(romp_net* n, int enable) {
     ROMP_REQUIRE(n, "romp_net_set_graph: null net");
     n->use_graph = enable ? 1 : 0;
@@ -240,22 +302,47 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
     if (!n->use_graph || n->mode != 0) return run_all(n, image, B, center, params, st);
-    GraphKey key{B, image, center, params};
-    auto it = n->graphs.find(key);
-    if (it == n->graphs.end()) {
-        ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
+    ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
+    auto capture = [&](hipStream_t origin, const GraphKey& key, auto&& body) -> int {
+        if (n->graphs.count(key)) return ROMP_OK;
         hipGraph_t g = nullptr;
-        ROMP_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        int rc = run_all(n, image, B, center, params, st);
-        hipError_t e = hipStreamEndCapture(st, &g);
+        ROMP_HIP_CHECK(hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal));
+        const int rc = body();
+        const hipError_t e = hipStreamEndCapture(origin, &g);
         if (rc) { if (g) hipGraphDestroy(g); return rc; }
         ROMP_HIP_CHECK(e);
         hipGraphExec_t ge = nullptr;
         ROMP_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         hipGraphDestroy(g);
-        it = n->graphs.emplace(key, ge).first;
+        n->graphs.emplace(key, ge);
+        return ROMP_OK;
+    };
+    if (!lanes_active(n, B)) {
+        const GraphKey key{B, image, center, params, -1};
+        const int rc = capture(st, key, [&] { return run_all(n, image, B, center, params, st); });
+        if (rc) return rc;
+        ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[key], st));
+        return ROMP_OK;
     }
-    ROMP_HIP_CHECK(hipGraphLaunch(it->second, st));
+    // Batch lanes: one graph per lane, replayed on the lane's own stream.  (Capturing both lanes with
+    // their branch side streams into ONE graph overflows the stack inside hipGraph on ROCm 7.2.)
+    const int B0 = B / 2;
+    const float* image1 = image + (size_t)B0 * n->image_floats;
+    float* center1 = center + (size_t)B0 * n->center_floats;
+    float* params1 = params + (size_t)B0 * n->params_floats;
+    const GraphKey k0{B, image, center, params, 0}, k1{B, image, center, params, 1};
+    int rc = capture(st, k0, [&] { return run_lane(n, image, B0, center, params, st, 0, 0, nullptr); });
+    if (rc) return rc;
+    rc = capture(n->lane_main, k1, [&] { return run_lane(n, image1, B0, center1, params1, n->lane_main, 1, B0, nullptr); });
+    if (rc) return rc;
+    rc = reset_queues(n, st);
+    if (rc) return rc;
+    ROMP_HIP_CHECK(hipEventRecord(n->ev_begin, st));
+    ROMP_HIP_CHECK(hipStreamWaitEvent(n->lane_main, n->ev_begin, 0));
+    ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[k0], st));
+    ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[k1], n->lane_main));
+    ROMP_HIP_CHECK(hipEventRecord(n->ev_done, n->lane_main));
+    ROMP_HIP_CHECK(hipStreamWaitEvent(st, n->ev_done, 0));
     return ROMP_OK;
 }
 
@@ -359,11 +446,17 @@ void romp_net_destroy(romp_net* n) {
     for (float* p : n->bufs)
         if (p) hipFree(p);
     if (n->queues) hipFree(n->queues);
-    for (int k = 0; k < 3; ++k) {
-        if (n->side[k]) hipStreamDestroy(n->side[k]);
-        if (n->ev_join[k]) hipEventDestroy(n->ev_join[k]);
+    for (int l = 0; l < 2; ++l) {
+        for (int k = 0; k < 3; ++k) {
+            if (n->side[l][k]) hipStreamDestroy(n->side[l][k]);
+            if (n->ev_join[l][k]) hipEventDestroy(n->ev_join[l][k]);
+        }
+        if (n->ev_fork[l]) hipEventDestroy(n->ev_fork[l]);
     }
-    if (n->ev_fork) hipEventDestroy(n->ev_fork);
+    if (n->lane_main) hipStreamDestroy(n->lane_main);
+    if (n->ev_begin) hipEventDestroy(n->ev_begin);
+    if (n->ev_offset) hipEventDestroy(n->ev_offset);
+    if (n->ev_done) hipEventDestroy(n->ev_done);
     delete n;
 }
 

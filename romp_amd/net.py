@@ -25,6 +25,7 @@ class RompNet:
         self.max_batch = int(max_batch)
         self.bf16x3 = bool(bf16x3)
         self._tuned = set()
+        self.split = 1
         self.input_size = input_size
         with torch.cuda.device(self.device):
             if builder is None:
@@ -57,6 +58,14 @@ class RompNet:
         """Run independent HRNet branches on side HIP streams (default on)."""
         L.check(self.lib.romp_net_set_streams(self._h, int(bool(enable))))
 
+    def set_split(self, lanes, wg_cap=1):
+        """lanes=2: run even batches as two half-batch lanes on two streams (convs capped at `wg_cap`
+        workgroups per CU so the lanes' kernels co-reside); kernel variants are then tuned for B/2."""
+        import math
+        L.check(self.lib.romp_net_set_split(self._h, int(lanes), int(wg_cap), self.input_size * self.input_size * 3,
+                                            math.prod(self.out_shapes[0]), math.prod(self.out_shapes[1])))
+        self.split = int(lanes)
+
     def set_graph(self, enable):
         L.check(self.lib.romp_net_set_graph(self._h, int(bool(enable))))
 
@@ -66,8 +75,9 @@ class RompNet:
         assert image.dtype == torch.float32 and image.is_cuda and image.dim() == 4 and image.shape[-1] == 3
         image = image.contiguous()
         B = image.shape[0]
-        if self.bf16x3 and B not in self._tuned:      # the bf16x3 kernels are only ever picked by measurement
-            self.autotune(B)
+        Bt = B // 2 if (self.split == 2 and B >= 2 and B % 2 == 0) else B     # batch the kernels really see
+        if self.bf16x3 and Bt not in self._tuned:     # the bf16x3 kernels are only ever picked by measurement
+            self.autotune(Bt)
         if center_out is None:
             center_out = torch.empty((B,) + tuple(self.out_shapes[0]), device=self.device, dtype=torch.float32)
         if params_out is None:

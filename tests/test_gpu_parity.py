@@ -304,6 +304,36 @@ def test_net_bf16x3_parity(dev, golden_dir):
     assert ec < 1e-4 and ep < 1e-4
 
 
+def test_net_batch_lanes(dev):
+    """set_split(2): the forward runs as two half-batch lanes on two streams (convs capped at one
+    workgroup per CU).  Same maps as the oracle for every image of the batch, eagerly and from a hipGraph;
+    odd batches fall back to one lane."""
+    from romp_amd.net import RompNet
+    sd = O.make_romp_state_dict(0)
+    net = RompNet(sd, dev, max_batch=4)
+    img = O.make_images(4, seed=6)
+    cm_o, pm_o = O.romp_net_forward(sd, img)
+    x = img.to(dev)
+    cm1, pm1 = net(x)
+    net.set_split(2, 1)
+    cm2, pm2 = net(x)
+    for name, (c, p) in {'one lane': (cm1, pm1), 'two lanes': (cm2, pm2)}.items():
+        ec, ep = (c.cpu() - cm_o).abs().max().item(), (p.cpu() - pm_o).abs().max().item()
+        print(f'{name}: center {ec:.3e} params {ep:.3e}')
+        assert ec < 1e-4 and ep < 1e-4
+    assert (cm2 - cm1).abs().max().item() < 2e-5 and (pm2 - pm1).abs().max().item() < 2e-5
+    c3, p3 = net(x[:3])                                    # odd batch: single lane
+    assert (c3 - cm2[:3]).abs().max().item() < 2e-5 and (p3 - pm2[:3]).abs().max().item() < 2e-5
+    net.set_graph(True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        xs = img.to(dev)
+        c4, p4 = net.forward_nhwc(xs)
+        c5, p5 = net.forward_nhwc(xs, c4.clone(), p4.clone())
+    s.synchronize()
+    assert torch.equal(c4.unsqueeze(1), cm2) and torch.equal(c5, c4) and torch.equal(p5, p4)
+
+
 def test_net_full_batch_properties(dev):
     """BASELINE config 2 size (B=32): images repeated inside the batch must give identical maps
     (no cross-image leakage, tile/batch indexing correct at full size), and a permuted batch must
