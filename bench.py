@@ -42,8 +42,8 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--center-thresh', type=float, default=1.3)
-    ap.add_argument('--workload', type=str, default='romp', choices=['romp', 'bev'],
-                    help="romp = BASELINE configs[1] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A)")
+    ap.add_argument('--workload', type=str, default='romp', choices=['romp', 'bev', 'smpl'],
+                    help="romp = BASELINE configs[1] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A); smpl = configs[4] (SMPL-only, 64 persons)")
     ap.add_argument('--graph', type=int, default=1, help='replay the network from a hipGraph')
     ap.add_argument('--conv-math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
                     help='f32: exact f32 MFMA kernels only; bf16x3: also offer the f32-accurate bf16x3-split kernels to the autotuner')
@@ -155,6 +155,61 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
                        '(reference onnxruntime path unavailable: module not installed)' % (n, Bc))
 
 
+def bench_smpl(args, dev):
+    """BASELINE configs[4]: SMPL-only microbench, 64 persons x 6890 verts (blend shapes + LBS + 71 joints), HIP vs
+    the torch-CPU oracle.  HBM-bound: per launch the kernels read betas/thetas, the blend-shape bases (v_template,
+    shapedirs, posedirs 17.1 MB, skinning weights) once per person tile from L2/HBM and write N x (6890 + 71) x 3 floats."""
+    import numpy as np
+    from romp_amd import synthetic as S
+    from romp_amd.smpl import SMPL
+    N = 64
+    model = S.make_smpl_model(0)
+    smpl = SMPL(model).to(dev)
+    g = torch.Generator().manual_seed(3)
+    betas = torch.randn(N, 10, generator=g).to(dev)
+    poses = (0.3 * torch.randn(N, 72, generator=g)).to(dev)
+    for _ in range(max(args.warmup, 3)):
+        v, j, _ = smpl(betas, poses)
+    torch.cuda.synchronize(dev)
+    steps = max(args.steps, 50)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        v, j, _ = smpl(betas, poses)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1) / steps
+    # algorithmic bytes per launch: bases read once + outputs written once
+    nb = 10
+    base_bytes = 4 * (6890 * 3 * (1 + nb) + 207 * 20670 + 6890 * 24 + (24 + 9 + 17) * 6890)
+    out_bytes = 4 * N * (6890 + 71) * 3
+    flops = 2.0 * N * (6890 * 3 * nb + 207 * 20670 + 6890 * 24 * 12 + 6890 * 12 + (9 + 17) * 6890 * 3)
+    res = {'metric': 'SMPL meshes/sec (64 persons x 6890 verts)', 'value': round(N * steps / dt, 1), 'unit': 'meshes/s', 'n_gpus': 1,
+           'steps': steps, 'warmup': max(args.warmup, 3), 'ms_per_step': round(dt / steps * 1e3, 4), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'SMPL-only: 64 persons, betas (64,10) + thetas (64,72) -> verts (64,6890,3), joints (64,71,3) (BASELINE configs[4])',
+                      'gpu_ms_per_launch': round(gpu_ms, 4)},
+           'roofline': {'bound': 'hbm', 'achieved': round((base_bytes + out_bytes) / (gpu_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': round((base_bytes + out_bytes) / (gpu_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
+                        'alg_bytes_per_launch': base_bytes + out_bytes, 'gflops_per_launch': round(flops / 1e9, 3),
+                        'note': 'five small kernels per launch (pose, skin, joints); launch latency bound at N=64'}}
+    if not args.no_cpu_baseline:
+        from oracle import romp_oracle as O
+        torch.set_num_threads(usable_cores())
+        bn, pn = betas.cpu().numpy(), poses.cpu().numpy()
+        vo, jo, _ = O.smpl_forward(model, bn, pn)
+        t0, n = time.time(), 0
+        while time.time() - t0 < min(args.cpu_seconds, 10.0) and n < 200:
+            O.smpl_forward(model, bn, pn); n += 1
+        cdt = time.time() - t0
+        res['cpu_baseline'] = dict(value=round(N * n / cdt, 1), unit='meshes/s', cores=torch.get_num_threads(), kind='port',
+                                   sample='%d calls of the torch-CPU restatement of smpl.py lbs at N=64' % n)
+        res['config']['verts_max_abs_vs_oracle'] = float(np.abs(v.cpu().numpy() - vo).max())
+    print(json.dumps(res), flush=True)
+
+
 def bench_bev(args, dev):
     """BASELINE configs[3]: BEV HRNet-32 + bird's-eye-view head, 512x512, batch 32, 1 GPU (not the headline line)."""
     from romp_amd import bev, synthetic as S
@@ -208,6 +263,8 @@ def main():
     lib = L.load()
     if args.workload == 'bev':
         return bench_bev(args, dev)
+    if args.workload == 'smpl':
+        return bench_smpl(args, dev)
     settings = romp_amd.romp_settings([])
     settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
     settings.conv_math = args.conv_math

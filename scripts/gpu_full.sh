@@ -21,5 +21,7 @@ for f in ('gpurun_out/bench.log',):
 EOF
 timeout 600 python bench.py --conv-math f32 --no-cpu-baseline > gpurun_out/bench_f32.log 2>&1
 echo "== bench f32: exit $? :: $(grep -o '"value": [0-9.]*' gpurun_out/bench_f32.log | head -1)"
+timeout 300 python bench.py --workload smpl > gpurun_out/bench_smpl.log 2>&1
+echo "== bench smpl: exit $? :: $(tail -c 1500 gpurun_out/bench_smpl.log)"
 timeout 600 python bench.py --workload bev > gpurun_out/bench_bev.log 2>&1
 echo "== bench bev: exit $? :: $(tail -c 700 gpurun_out/bench_bev.log)"
