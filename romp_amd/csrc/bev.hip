@@ -8,7 +8,7 @@
 //
 //   bev_pack_kernel     front-view maps (B,128,128,{4,16}) NHWC -> Conv1d input (B, W=128, (c,h)=2560)
 //   bev_maps_kernel     center_map_3d = center_fv (x) center_bv ; cam_maps_3d = coordmap + offsets
-//   conv3d_kernel<C>    3x3x3 stencil on 1 / 3 channels (NCDHW volumes 64x128x128): HBM-bound
+//   conv3d_kernel<C>    3x3x3 conv on 1 / 3 channels (NCDHW volumes 64x128x128): LDS slice ring, marches along D
 //   bev_nms_kernel + bev_rank_kernel + bev_compact_kernel   MaxPool3d(5) NMS + ordered top-K
 //   bev_regress_kernel  per person: cam gather, anchor argmin, feature + depth embedding, 3-layer MLP,
 //                       rot6D -> axis-angle, SMPL-A betas, camera -> translation
@@ -65,53 +65,93 @@ struct Conv3dParams {
     int relu;
 };
 
-// NCDHW volumes (D=64,H=128,W=128); one thread per voxel computes all C output channels.
+// 3x3x3 convolution + folded BN (+ residual) (+ ReLU) on NCDHW volumes (D=64, H=128, W=128), C in {1,3}
+// channels in and out (BasicBlock_3D, bev/model.py:52-75).  Arithmetic intensity 2*27*C FLOP per 4-byte
+// voxel read: VALU/HBM balanced, far too thin for the matrix pipe.  A workgroup owns a (T3_D x T3_H x 128)
+// output brick and marches along D with a ring of three haloed input slices in LDS (one new slice per
+// step, all C channels); a thread produces 4 consecutive voxels along W for every output channel from
+// float4 + float2 row-segment reads (conflict-free), weights come in as scalar operands from the kernel
+// arguments.  Loads and stores are full 512-byte rows.
+constexpr int T3_H = 8, T3_D = 16, T3_RW = BM + 8;            // row pitch in floats: 4 left pad (halo at [3]) + 128 + 4
+
 template <int C>
 __global__ __launch_bounds__(256) void conv3d_kernel(Conv3dParams p, int B) {
-    __shared__ float s_w[C * C * 27];
-    for (int i = threadIdx.x; i < C * C * 27; i += 256) s_w[i] = p.w[i];
+    constexpr int SLICE = C * (T3_H + 2) * T3_RW;               // floats per ring slot
+    __shared__ __attribute__((aligned(16))) float ring[3 * SLICE];
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int hb = t % (BM / T3_H); t /= (BM / T3_H);
+    const int db = t % (BD / T3_D);
+    const int b = t / (BD / T3_D);
+    const int h0 = hb * T3_H, d0 = db * T3_D;
+    const float* inb = p.in + (size_t)b * C * BVOX;
+    // zero the pads once (columns -1 and 128 of every row stay zero: the brick spans the full W)
+    for (int i = tid; i < 3 * SLICE; i += 256) ring[i] = 0.f;
     __syncthreads();
-    const size_t total = (size_t)B * BVOX;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t r = i;
-        const int w = r % BM; r /= BM;
-        const int h = r % BM; r /= BM;
-        const int d = r % BD;
-        const int b = r / BD;
-        float acc[C];
+    auto load_slice = [&](int d, int slot) {                     // slice d (may be outside: zeros), rows h0-1 .. h0+T3_H
+        float* dst = ring + slot * SLICE;
+        for (int i = tid; i < C * (T3_H + 2) * (BM / 4); i += 256) {
+            const int q = i % (BM / 4);
+            int r = i / (BM / 4);
+            const int row = r % (T3_H + 2);
+            const int ci = r / (T3_H + 2);
+            const int h = h0 - 1 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)d < (unsigned)BD && (unsigned)h < (unsigned)BM)
+                v = *reinterpret_cast<const float4*>(inb + (size_t)ci * BVOX + ((size_t)d * BM + h) * BM + q * 4);
+            *reinterpret_cast<float4*>(dst + (ci * (T3_H + 2) + row) * T3_RW + 4 + q * 4) = v;
+        }
+    };
+    load_slice(d0 - 1, 0);
+    load_slice(d0, 1);
+    const int q = tid & 31, hr = tid >> 5;                       // 4 voxels w = 4q..4q+3 of row h0 + hr
+    for (int dd = 0; dd < T3_D; ++dd) {
+        load_slice(d0 + dd + 1, (dd + 2) % 3);
+        __syncthreads();
+        float acc[C][4];
 #pragma unroll
-        for (int co = 0; co < C; ++co) acc[co] = 0.f;
-        const float* inb = p.in + (size_t)b * C * BVOX;
+        for (int co = 0; co < C; ++co)
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) {
-            for (int dz = -1; dz <= 1; ++dz) {
-                const int zz = d + dz;
-                if ((unsigned)zz >= (unsigned)BD) continue;
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int yy = h + dy;
-                    if ((unsigned)yy >= (unsigned)BM) continue;
-                    const float* row = inb + (size_t)ci * BVOX + ((size_t)zz * BM + yy) * BM;
+            for (int j = 0; j < 4; ++j) acc[co][j] = 0.f;
+#pragma unroll 1
+        for (int ci = 0; ci < C; ++ci)
+#pragma unroll 1
+            for (int dz = 0; dz < 3; ++dz) {
+                const float* sl = ring + ((dd + dz) % 3) * SLICE + (ci * (T3_H + 2) + hr) * T3_RW + q * 4;
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int xx = w + dx;
-                        if ((unsigned)xx >= (unsigned)BM) continue;
-                        const float x = row[xx];
-                        const int tap = ((dz + 1) * 3 + (dy + 1)) * 3 + (dx + 1);
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float* row = sl + dy * T3_RW;
+                    const float xm = row[3];                                         // w = 4q - 1
+                    const float4 x4 = *reinterpret_cast<const float4*>(row + 4);     // w = 4q .. 4q+3
+                    const float xp = row[8];                                         // w = 4q + 4
+                    const float x[6] = {xm, x4.x, x4.y, x4.z, x4.w, xp};
 #pragma unroll
-                        for (int co = 0; co < C; ++co) acc[co] = fmaf(x, s_w[(co * C + ci) * 27 + tap], acc[co]);
-                    }
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int co = 0; co < C; ++co) {
+                            const float wv = p.w[(co * C + ci) * 27 + (dz * 3 + dy) * 3 + dx];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(x[j + dx], wv, acc[co][j]);
+                        }
                 }
             }
-        }
-        const size_t vox = ((size_t)d * BM + h) * BM + w;
+        const int d = d0 + dd, h = h0 + hr;
 #pragma unroll
         for (int co = 0; co < C; ++co) {
-            float v = fmaf(acc[co], p.scale[co], p.shift[co]);
-            const size_t o = (size_t)b * C * BVOX + (size_t)co * BVOX + vox;
-            if (p.res) v += p.res[o];
-            if (p.relu) v = fmaxf(v, 0.f);
-            p.out[o] = v;
+            const size_t o = (size_t)b * C * BVOX + (size_t)co * BVOX + ((size_t)d * BM + h) * BM + q * 4;
+            float4 v;
+            v.x = fmaf(acc[co][0], p.scale[co], p.shift[co]);
+            v.y = fmaf(acc[co][1], p.scale[co], p.shift[co]);
+            v.z = fmaf(acc[co][2], p.scale[co], p.shift[co]);
+            v.w = fmaf(acc[co][3], p.scale[co], p.shift[co]);
+            if (p.res) {
+                const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(p.out + o) = v;
         }
+        __syncthreads();                                         // everyone done with slot dd%3 before it is reloaded
     }
 }
 
@@ -139,8 +179,9 @@ int launch_conv3d(int C, const float* w_host, const float* scale_host, const flo
     p.in = in; p.res = res; p.out = out; p.relu = relu;
     for (int i = 0; i < C * C * 27; ++i) p.w[i] = w_host[i];
     for (int i = 0; i < C; ++i) { p.scale[i] = scale_host[i]; p.shift[i] = shift_host[i]; }
-    if (C == 1) hipLaunchKernelGGL(conv3d_kernel<1>, dim3(8192), dim3(256), 0, st, p, B);
-    else hipLaunchKernelGGL(conv3d_kernel<3>, dim3(8192), dim3(256), 0, st, p, B);
+    const int grid = B * (BD / T3_D) * (BM / T3_H);
+    if (C == 1) hipLaunchKernelGGL(conv3d_kernel<1>, dim3(grid), dim3(256), 0, st, p, B);
+    else hipLaunchKernelGGL(conv3d_kernel<3>, dim3(grid), dim3(256), 0, st, p, B);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

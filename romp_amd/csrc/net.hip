@@ -476,6 +476,9 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_FUSESUM) { snprintf(out, n, "fusesum"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_BEV_PACK) { snprintf(out, n, "bev_pack"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_BEV_MAPS) { snprintf(out, n, "bev_maps"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_CONV3D) { snprintf(out, n, "conv3d"); return ROMP_OK; }
     ROMP_REQUIRE(op->kind == ROMP_OP_CONV, "romp_conv_describe: op kind %d", op->kind);
     if (variant >= 0 && !conv_variant_valid(*op, variant)) { set_error("variant %d not valid for this op", variant); return ROMP_EINVAL; }
     return describe_conv(*op, B, variant, out, n);

@@ -1,5 +1,5 @@
 """Per-op table of the tuned network at batch B (GPU): variant, ms, GFLOP, TFLOP/s, algorithmic GB/s.
-usage: python scripts/op_table.py [B] [f32|bf16x3]"""
+usage: python scripts/op_table.py [B] [f32|bf16x3] [romp|bev]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,13 @@ from romp_amd.net import RompNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 math = sys.argv[2] if len(sys.argv) > 2 else 'bf16x3'
 dev = torch.device('cuda:0')
-net = RompNet(S.make_romp_state_dict(0), dev, max_batch=B, bf16x3=(math == 'bf16x3'))
+if len(sys.argv) > 3 and sys.argv[3] == 'bev':
+    from oracle import bev_oracle as BO
+    from romp_amd.bev_plan import build_bev_hrnet32
+    net = RompNet(BO.make_bev_state_dict(0), dev, max_batch=B, builder=build_bev_hrnet32,
+                  out_shapes=((64, 128, 128), (3, 64, 128, 128)), bf16x3=(math == 'bf16x3'))
+else:
+    net = RompNet(S.make_romp_state_dict(0), dev, max_batch=B, bf16x3=(math == 'bf16x3'))
 x = S.make_images(B, seed=1, device=dev)
 net.autotune(B)
 s = torch.cuda.Stream()
@@ -21,6 +27,8 @@ for i, (nm, t) in enumerate(zip(names, ms)):
     if nm in ('fork', 'join'):
         continue
     op = P.ops[i]
+    if P.names[i].startswith('bev.'):
+        print('  %-28s %-36s %8.3f ms  %7.1f GF  %8.1f MB' % (P.names[i], nm, t, P.flops[i] * B / 1e9, P.bytes[i] * B / 1e6))
     rows.append((t, P.names[i], nm, op.H, op.W, op.Cin, op.Cout, P.flops[i] * B / 1e9, P.bytes[i] * B / 1e6))
 tot = sum(r[0] for r in rows)
 print('total serial ms %.3f over %d ops' % (tot, len(rows)))
