@@ -203,6 +203,11 @@ void smpl_ctx_destroy(smpl_ctx* ctx);
 int  romp_project(const float* joints, int N, int J, const float* cam, const float* pad_info_host,
                   float* pj2d, float* pj2d_org, float* cam_trans, void* stream);
 
+/* Vertices of the meshes for rendering: verts_camed = batch_orth_proj(verts, cam, '3d', keep_dim) and its
+ * original-image version (post_parser.py:81-88,108,113).  verts (N,V,3); verts_camed may be NULL. */
+int  romp_project_verts(const float* verts, int N, int V, const float* cam, const float* pad_info_host,
+                        float* verts_camed, float* verts_camed_org, void* stream);
+
 /* ------------------------------------------------------------------ callers either side */
 
 /* img_preprocess (utils.py:16-30) on device: BGR uint8 (H,W,3) -> RGB float32 (S,S,3) 0..255, centred zero
@@ -217,6 +222,24 @@ int  romp_preprocess(const unsigned char* bgr_u8, int H, int W, float* out_rgb_f
 int  romp_bev_postprocess(const float* joints /* (N,71,3) */, const float* cam /* (N,3) */, const int32_t* offsets,
                           int B, const float* pad_info, float nms_thresh, float relative_scale_thresh,
                           float* pj2d, float* pj2d_org, float* cam_trans, int32_t* keep, void* stream);
+
+/* ---- Sim3DR mesh renderer -------------------------------------------------
+ * Replaces the Cython/C++ extension `Sim3DR_Cython` (simple_romp/vis_human/sim3drender/lib/rasterize.pyx,
+ * rasterize_kernel.cpp) and the per-vertex lighting of renderer.py:64-110.  Bit-identical images.
+ * All pointers are device pointers unless named *_host. */
+/* _get_normal (rasterize_kernel.cpp:171-229).  adj_off[nver+1] / adj_ent[3*ntri]: for each vertex the
+ * ascending list of flattened corner indices 3*t+k that reference it (built once per topology). */
+int  romp_sim3dr_normals(const float* verts, const int32_t* tris, const int32_t* adj_off, const int32_t* adj_ent,
+                         int nver, float* normals, void* stream);
+/* Sim3DR.render lighting (renderer.py:77-110).  cfg_host[14] = ambient rgb (intensity_ambient*color as
+ * float32), intensity_directional, intensity_specular (0 = off), color_directional rgb, light_pos xyz,
+ * view_pos xyz; specular_exp is 1. */
+int  romp_sim3dr_light(const float* verts, const float* normals, int nver, const float* cfg_host, float* light,
+                       void* stream);
+/* _rasterize (rasterize_kernel.cpp:233-300) with alpha = 1, in place on image (h,w,c) uint8; vertices in
+ * pixel coordinates, larger z = nearer; keys: h*w 64-bit words of scratch. */
+int  romp_sim3dr_rasterize(unsigned char* image, const float* verts, const int32_t* tris, const float* colors,
+                           int ntri, int h, int w, int c, int reverse, unsigned long long* keys, void* stream);
 
 #ifdef __cplusplus
 }

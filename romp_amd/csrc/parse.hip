@@ -149,11 +149,38 @@ __global__ void project_kernel(const float* __restrict__ joints, int N, int J, c
     }
 }
 
+// batch_orth_proj(mode='3d', keep_dim=True) + convert_proejection_from_input_to_orgimg on (N,V,3) vertices
+// (post_parser.py:81-88,108,113; utils.py:309-315): x,y projected, z kept; then all three to original-image pixels.
+#pragma clang fp contract(off)   // mul, then add, like the reference's two tensor ops: the renderer's z-test sees these bits
+__global__ void project_verts_kernel(const float* __restrict__ verts, size_t total, int V, const float* __restrict__ cam,
+                                     float pad_size, float left, float top, float* __restrict__ camed, float* __restrict__ org) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = i / V;
+    const float s = cam[n * 3], tx = cam[n * 3 + 1], ty = cam[n * 3 + 2];
+    const float px = verts[i * 3] * s + tx, py = verts[i * 3 + 1] * s + ty, pz = verts[i * 3 + 2];
+    if (camed) { camed[i * 3] = px; camed[i * 3 + 1] = py; camed[i * 3 + 2] = pz; }
+    org[i * 3] = (px + 1.f) * pad_size / 2.f - left;
+    org[i * 3 + 1] = (py + 1.f) * pad_size / 2.f - top;
+    org[i * 3 + 2] = (pz + 1.f) * pad_size / 2.f;
+}
+
 }  // namespace romp
 
 using namespace romp;
 
 extern "C" {
+
+int romp_project_verts(const float* verts, int N, int V, const float* cam, const float* pad_info_host, float* verts_camed,
+                       float* verts_camed_org, void* stream) {
+    ROMP_REQUIRE(verts && cam && pad_info_host && verts_camed_org && N > 0 && V > 0, "romp_project_verts: bad arguments");
+    const float top = pad_info_host[0], left = pad_info_host[2], h = pad_info_host[4], w = pad_info_host[5];
+    const size_t total = (size_t)N * V;
+    hipLaunchKernelGGL(project_verts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, total, V,
+                       cam, h > w ? h : w, left, top, verts_camed, verts_camed_org);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
 
 int romp_parse(const float* center_maps, const float* params_maps, int B, float conf_thresh, int max_person,
                int32_t* count_host, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,

@@ -22,6 +22,7 @@ from . import lib as L
 from .net import RompNet
 from .post_parser import (CenterMap, SMPL_parser, body_mesh_projection2image, convert_cam_to_3d_trans,
                           parsing_outputs)
+from .vis import rendering_romp_bev_results, setup_renderer
 from .utils import ResultSaver, convert_tensor2numpy, determine_device, img_preprocess, img_preprocess_device
 
 
@@ -81,8 +82,8 @@ class ROMP(nn.Module):
         if self.settings.GPU == -1:
             raise L.RompHipError('romp_amd is the MI355X path of ROMP: it needs a HIP device (GPU=%d); '
                                  'there is no CPU fallback' % self.settings.GPU)
-        if self.settings.render_mesh or self.settings.temporal_optimize:
-            raise NotImplementedError('rendering / temporal smoothing are outside the MI355X hot path (SURVEY.md §8f)')
+        if self.settings.temporal_optimize:
+            raise NotImplementedError('temporal smoothing is outside the MI355X hot path (SURVEY.md §8f-4)')
         self.tdevice = determine_device(self.settings.GPU)
         self._build_model_(state_dict)
         self._initilization_(smpl_model)
@@ -98,6 +99,9 @@ class ROMP(nn.Module):
         self.centermap_parser = CenterMap(conf_thresh=self.settings.center_thresh)
         if self.settings.calc_smpl:
             self.smpl_parser = SMPL_parser(smpl_model if smpl_model is not None else self.settings.smpl_path).to(self.tdevice)
+        if self.settings.render_mesh:                                                       # main.py:101-103
+            self.visualize_items = self.settings.show_items.split(',')
+            self.renderer = setup_renderer(name=self.settings.renderer, device=self.tdevice)
 
     def single_image_forward(self, image):
         """main.py:106-115."""
@@ -114,7 +118,8 @@ class ROMP(nn.Module):
         outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])                      # main.py:166
         if self.settings.calc_smpl:
             outputs = self.smpl_parser(outputs, root_align=self.settings.root_align)        # main.py:168
-            outputs.update(body_mesh_projection2image(outputs['joints'], outputs['cam'], vertices=outputs['verts'],
+            outputs.update(body_mesh_projection2image(outputs['joints'], outputs['cam'],
+                                                      vertices=outputs['verts'] if self.settings.render_mesh else None,
                                                       input2org_offsets=image_pad_info))   # main.py:169
         return outputs
 
@@ -123,7 +128,11 @@ class ROMP(nn.Module):
         outputs, image_pad_info = self.single_image_forward(image)
         if outputs is None:
             return None
-        return convert_tensor2numpy(self._finish(outputs, image_pad_info))
+        outputs = self._finish(outputs, image_pad_info)
+        if self.settings.render_mesh:                                                       # main.py:170-172
+            rendering_cfgs = {'mesh_color': 'identity', 'items': self.visualize_items, 'renderer': self.settings.renderer}
+            outputs = rendering_romp_bev_results(self.renderer, outputs, image, rendering_cfgs)
+        return convert_tensor2numpy(outputs)
 
     @torch.no_grad()
     def forward_batch(self, images, return_tensors=True):

@@ -171,6 +171,14 @@ def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_of
     out = {'pj2d': pj2d, 'cam_trans': torch.from_numpy(trans).float().to(dev)}
     if input2org_offsets is not None:
         out['pj2d_org'] = pj2d_org
+    if vertices is not None:                                           # post_parser.py:107-113 (dropped again before return unless rendering)
+        v = vertices.contiguous().float()
+        camed, org = torch.empty_like(v), torch.empty_like(v)
+        with torch.cuda.device(dev):
+            L.check(lib.romp_project_verts(L.ptr(v), v.shape[0], v.shape[1], L.ptr(cam), pad_c, L.ptr(camed), L.ptr(org), L.stream_ptr(dev)))
+        out['verts_camed'] = camed
+        if input2org_offsets is not None:
+            out['verts_camed_org'] = org
     return out
 
 
