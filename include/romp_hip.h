@@ -241,6 +241,15 @@ int  romp_sim3dr_light(const float* verts, const float* normals, int nver, const
 int  romp_sim3dr_rasterize(unsigned char* image, const float* verts, const int32_t* tris, const float* colors,
                            int ntri, int h, int w, int c, int reverse, unsigned long long* keys, void* stream);
 
+/* ---- temporal smoothing ---------------------------------------------------
+ * OneEuro filters of smooth_results (simple_romp/romp/utils.py:188-269) for N tracked persons, in place on
+ * thetas (N,72), betas (N,n_betas), cam (N,3).  state: caller-owned device buffer of
+ * romp_oneeuro_state_floats(n_betas) floats per track slot, zeroed when a slot is (re)assigned;
+ * slots[N]: the slot of each row (device).  smooth_coeff: --smooth_coeff (mincutoff of the pose filters). */
+int  romp_oneeuro_state_floats(int n_betas);
+int  romp_oneeuro_smooth(float* state, const int32_t* slots, int N, int n_betas, float smooth_coeff,
+                         float* thetas, float* betas, float* cam, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,8 +82,6 @@ class ROMP(nn.Module):
         if self.settings.GPU == -1:
             raise L.RompHipError('romp_amd is the MI355X path of ROMP: it needs a HIP device (GPU=%d); '
                                  'there is no CPU fallback' % self.settings.GPU)
-        if self.settings.temporal_optimize:
-            raise NotImplementedError('temporal smoothing is outside the MI355X hot path (SURVEY.md §8f-4)')
         self.tdevice = determine_device(self.settings.GPU)
         self._build_model_(state_dict)
         self._initilization_(smpl_model)
@@ -99,6 +97,17 @@ class ROMP(nn.Module):
         self.centermap_parser = CenterMap(conf_thresh=self.settings.center_thresh)
         if self.settings.calc_smpl:
             self.smpl_parser = SMPL_parser(smpl_model if smpl_model is not None else self.settings.smpl_path).to(self.tdevice)
+        if self.settings.temporal_optimize:                                                 # main.py:98-99, :105-116
+            self.OE_filters = {}
+            if not self.settings.show_largest:
+                try:
+                    from norfair import Tracker
+                except ImportError:
+                    raise NotImplementedError('multi-person temporal smoothing associates persons with the third-party norfair '
+                                              'tracker (main.py:108-116), which is not installed; use --show_largest')
+                from .utils import euclidean_distance
+                self.tracker = Tracker(distance_function=euclidean_distance, distance_threshold=200)
+                self.tracker_initialized = False
         if self.settings.render_mesh:                                                       # main.py:101-103
             self.visualize_items = self.settings.show_items.split(',')
             self.renderer = setup_renderer(name=self.settings.renderer, device=self.tdevice)
@@ -114,6 +123,37 @@ class ROMP(nn.Module):
         parsed_results = parsing_outputs(center_maps, params_maps, self.centermap_parser)
         return parsed_results, image_pad_info
 
+    def temporal_optimization(self, outputs, signal_ID):
+        """main.py:117-157: OneEuro smoothing of thetas / betas / cam, per tracked person (or of the largest
+        person with --show_largest).  Filters on the device (temporal.py / csrc/temporal.hip)."""
+        from .temporal import OneEuroBank
+        if signal_ID not in self.OE_filters:                                                # check_filter_state (utils.py:246-255)
+            if len(self.OE_filters) > 100:
+                self.OE_filters.clear()
+            self.OE_filters[signal_ID] = OneEuroBank(self.tdevice, self.settings.smooth_coeff, outputs['smpl_betas'].shape[1])
+        bank = self.OE_filters[signal_ID]
+        if self.settings.show_largest:
+            max_id = int(torch.argmax(outputs['cam'][:, 0]))
+            th, be, ca = (outputs[k][max_id:max_id + 1].contiguous().clone() for k in ('smpl_thetas', 'smpl_betas', 'cam'))
+            outputs['smpl_thetas'], outputs['smpl_betas'], outputs['cam'] = bank.smooth([0], th, be, ca)
+            return outputs
+        import numpy as np
+        from norfair import Detection
+        from .utils import get_tracked_ids
+        detections = [Detection(points=cam[[2, 1]] * 512) for cam in outputs['cam'].cpu().numpy()]
+        if not self.tracker_initialized:
+            for _ in range(8):
+                self.tracker.update(detections=detections)
+            self.tracker_initialized = True
+        tracked_objects = self.tracker.update(detections=detections)
+        if len(tracked_objects) == 0:
+            return outputs
+        tracked_ids = get_tracked_ids(detections, tracked_objects)
+        th, be, ca = (outputs[k].contiguous() for k in ('smpl_thetas', 'smpl_betas', 'cam'))
+        outputs['smpl_thetas'], outputs['smpl_betas'], outputs['cam'] = bank.smooth(tracked_ids, th, be, ca)
+        outputs['track_ids'] = np.array(tracked_ids).astype(np.int32)
+        return outputs
+
     def _finish(self, outputs, image_pad_info):
         outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])                      # main.py:166
         if self.settings.calc_smpl:
@@ -128,6 +168,8 @@ class ROMP(nn.Module):
         outputs, image_pad_info = self.single_image_forward(image)
         if outputs is None:
             return None
+        if self.settings.temporal_optimize:                                                 # main.py:164-165
+            outputs = self.temporal_optimization(outputs, signal_ID)
         outputs = self._finish(outputs, image_pad_info)
         if self.settings.render_mesh:                                                       # main.py:170-172
             rendering_cfgs = {'mesh_color': 'identity', 'items': self.visualize_items, 'renderer': self.settings.renderer}

@@ -1,0 +1,39 @@
+"""Temporal smoothing of the per-person estimates (video / webcam mode, ``-t``): mirror of
+``simple_romp/romp/utils.py`` ``create_OneEuroFilter`` / ``smooth_results`` / ``check_filter_state`` (:246-269)
+and of ``ROMP.temporal_optimization`` (``main.py:117-157``).  The filters run on the device
+(``romp_oneeuro_smooth``, csrc/temporal.hip); this module only keeps the track -> state-slot table.
+"""
+import torch
+
+from . import lib as L
+
+
+class OneEuroBank(object):
+    """Filter states of up to `capacity` tracks (per signal source) in one device buffer."""
+
+    def __init__(self, device, smooth_coeff=3., n_betas=10, capacity=256):
+        self.device, self.smooth_coeff, self.n_betas = torch.device(device), float(smooth_coeff), int(n_betas)
+        self.lib = L.load()
+        self.stride = self.lib.romp_oneeuro_state_floats(self.n_betas)
+        self.state = torch.zeros(capacity, self.stride, device=self.device)
+        self.slots = {}                                   # track id -> row of self.state
+
+    def _slot(self, tid):
+        if tid not in self.slots:
+            if len(self.slots) >= self.state.shape[0]:    # utils.py:253-254 drops all filters of a source that has grown too large
+                self.slots.clear()
+                self.state.zero_()
+            used = set(self.slots.values())
+            s = next(i for i in range(self.state.shape[0]) if i not in used)
+            self.state[s].zero_()
+            self.slots[tid] = s
+        return self.slots[tid]
+
+    def smooth(self, track_ids, thetas, betas, cam):
+        """In place on thetas (N,72), betas (N,nb), cam (N,3) (device float32, contiguous); returns them."""
+        assert thetas.is_contiguous() and betas.is_contiguous() and cam.is_contiguous() and thetas.dtype == torch.float32
+        slots = torch.tensor([self._slot(t) for t in track_ids], dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.romp_oneeuro_smooth(L.ptr(self.state), L.ptr(slots), len(track_ids), self.n_betas, self.smooth_coeff,
+                                                 L.ptr(thetas), L.ptr(betas), L.ptr(cam), L.stream_ptr(self.device)))
+        return thetas, betas, cam

@@ -150,3 +150,15 @@ class WebcamVideoStream(object):
 
     def stop(self):
         self.stopped = True
+
+
+def euclidean_distance(detection, tracked_object):
+    """utils.py:272-273 (norfair distance function)."""
+    return np.linalg.norm(detection.points - tracked_object.estimate)
+
+
+def get_tracked_ids(detections, tracked_objects):
+    """utils.py:275-280: id of the nearest tracked object for every detection."""
+    ids = np.array([obj.id for obj in tracked_objects])
+    tracked = np.array([obj.last_detection.points[0] for obj in tracked_objects])
+    return [ids[np.argmin(np.linalg.norm(tracked - np.asarray(d.points)[None], axis=1))] for d in detections]
