@@ -28,8 +28,11 @@ void set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// work queues of the persistent conv kernels: 8 counters (one per XCD), each on its own 128-byte line
+constexpr int QUEUE_STRIDE = 32, QUEUE_INTS = 8 * QUEUE_STRIDE;
+
 // launchers implemented in the kernel translation units
-// variant < 0: heuristic choice; queue: 8 zeroed ints (nullptr: library scratch, memset on `st`)
+// variant < 0: heuristic choice; queue: QUEUE_INTS zeroed ints (nullptr: library scratch, memset on `st`)
 // wg_cap > 0: at most that many workgroups per CU (room for a co-resident kernel of another stream)
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B,
                 int mode, int variant, int* queue, hipStream_t st, int wg_cap = 0);

@@ -37,7 +37,7 @@ struct ConvParams {
     const float* in; const float* w; const float* scale; const float* shift; const float* res;
     float* out;
     const uint4* w3;          // bf16x3-split weights (conv_bx3_kernel), or nullptr
-    int* queue;               // 8 per-XCD work counters, zeroed before the launch
+    int* queue;               // 8 per-XCD work counters, QUEUE_STRIDE ints apart, zeroed before the launch
     int H, W, Ho, Wo;
     int Cout;                 // valid output channels per group (store mask)
     int cin_valid;            // channels physically present in the input (loader mask)
@@ -211,6 +211,7 @@ __device__ __forceinline__ void mma_stage(const float* sA, const float* sB, cons
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+    if (p.dbg & 32) return;                            // ablation: launch cost only
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;                                  // haloed pixels
@@ -224,14 +225,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
 
-    // ---- work queue: fetch the first two items synchronously, later ones a whole item ahead
-    if (tid == 0) {
-        sQ[0] = atomicAdd(p.queue + q, 1);
-        sQ[1] = atomicAdd(p.queue + q, 1);
-    }
-    __syncthreads();
-    int j_cur = sQ[0], j_next = sQ[1];
-    if (j_cur >= p.per_queue) return;
+    // ---- work queue: the first item is static (this workgroup's rank within its queue -- no atomic round
+    // trip before the first loads), every later one is counter + workgroups-per-queue, fetched a whole item
+    // ahead.  The 8 per-XCD counters sit QUEUE_STRIDE ints apart (one cache line each).
+    const int nwg_q = gridDim.x / p.n_queues;
+    const int j_cur0 = blockIdx.x / p.n_queues;
+    if (j_cur0 >= p.per_queue) return;
+    if (tid == 0) sQ[1] = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
+    int j_cur = j_cur0;
 
     float4 ra[C::NA], rb[C::NB];
     float rs = 0.f;                                    // one scale-or-shift value (threads < 2*NW)
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     Item cur = decode_item(p, q, j_cur, C::NW);
     issue_loads(cur, 0);
     write_lds(true, 0);
-    __syncthreads();
+    __syncthreads();                                   // stage 0 in LDS; also publishes sQ[1]
+    int j_next = sQ[1];
     int slot = 0, ch = 0;
     Item nxt = cur;
     bool have_next = j_next < p.per_queue;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const bool pf = !last || have_next;          // is there a next stage to prefetch?
         Item tgt = last ? nxt : cur;
         const int c0 = last ? 0 : (ch + 1) * CK;
-        if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);   // item after next
+        if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;   // item after next
         if (pf && !(p.dbg & 1)) issue_loads(tgt, c0);
         if (!(p.dbg & 8)) mma_stage<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
         if (ch == 0 && tid == 0) sQ[0] = j_after;
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 // its MFMA phase.  One workgroup-wide barrier per phase.  2 waves/SIMD => up to 256 VGPRs per wave.
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
+    if (p.dbg & 32) return;                            // ablation: launch cost only
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
     constexpr int GROUP_FLOATS = C::LDS_BYTES / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -382,8 +385,8 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
     const int n_chunks = p.cin_pad / CK;
 
     if (tid == 0) {
-        sQ[0] = atomicAdd(p.queue + q, 1);
-        sQ[1] = atomicAdd(p.queue + q, 1);
+        sQ[0] = atomicAdd(p.queue + q * QUEUE_STRIDE, 1);
+        sQ[1] = atomicAdd(p.queue + q * QUEUE_STRIDE, 1);
         sQ[2] = 0;
     }
     __syncthreads();
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
                 pf = !last || have_next;
                 Item tgt = last ? nxt : cur;
                 const int c0 = last ? 0 : (ch + 1) * CK;
-                if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
+                if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1);
                 if (pf) issue_loads(tgt, c0);
                 mma_stage<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
                 if (ch == 0 && tid == 0) sQ[0] = j_after;
@@ -606,6 +609,7 @@ __device__ __forceinline__ void mma_stage_bx3(const char* sA, const char* sB, co
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
+    if (p.dbg & 32) return;                            // ablation: launch cost only
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
     using X = BxCfg<KS, S, MT, NT, TW, CK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -620,13 +624,11 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
 
-    if (tid == 0) {
-        sQ[0] = atomicAdd(p.queue + q, 1);
-        sQ[1] = atomicAdd(p.queue + q, 1);
-    }
-    __syncthreads();
-    int j_cur = sQ[0], j_next = sQ[1];
-    if (j_cur >= p.per_queue) return;
+    const int nwg_q = gridDim.x / p.n_queues;
+    const int j_cur0 = blockIdx.x / p.n_queues;
+    if (j_cur0 >= p.per_queue) return;
+    if (tid == 0) sQ[1] = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
+    int j_cur = j_cur0;
 
     float4 ra[C::NA];
     uint4 rb[X::NB];
@@ -712,7 +714,8 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
     Item cur = decode_item(p, q, j_cur, C::NW);
     issue_loads(cur, 0);
     write_lds(true, 0);
-    __syncthreads();
+    __syncthreads();                                   // stage 0 in LDS; also publishes sQ[1]
+    int j_next = sQ[1];
     int slot = 0, ch = 0;
     Item nxt = cur;
     bool have_next = j_next < p.per_queue;
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
         const bool pf = !last || have_next;
         Item tgt = last ? nxt : cur;
         const int c0 = last ? 0 : (ch + 1) * CK;
-        if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
+        if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
         if (pf && !(p.dbg & 1)) issue_loads(tgt, c0);
         if (!(p.dbg & 8)) mma_stage_bx3<KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
         if (ch == 0 && tid == 0) sQ[0] = j_after;
@@ -793,6 +796,7 @@ struct BdCfg {
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
+    if (p.dbg & 32) return;                            // ablation: launch cost only
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
     using X = BdCfg<KS, S, MT, NT, TW, CK>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -808,13 +812,11 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
     const int n_chunks = p.cin_pad / CK;
     const int cin16 = p.cin_pad >> 4;
 
-    if (tid == 0) {
-        sQ[0] = atomicAdd(p.queue + q, 1);
-        sQ[1] = atomicAdd(p.queue + q, 1);
-    }
-    __syncthreads();
-    int j_cur = sQ[0], j_next = sQ[1];
-    if (j_cur >= p.per_queue) return;
+    const int nwg_q = gridDim.x / p.n_queues;
+    const int j_cur0 = blockIdx.x / p.n_queues;
+    if (j_cur0 >= p.per_queue) return;
+    if (tid == 0) sQ[1] = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
+    int j_cur = j_cur0;
 
     float4 ra[C::NA];
     float rs = 0.f;
@@ -897,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
     issue_A(cur, 0);
     write_A(true, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();                                   // stage 0 in LDS; also publishes sQ[1]
+    int j_next = sQ[1];
     int slot = 0, ch = 0, row = 0, bbuf = 0, par = 0;
     Item nxt = cur;
     bool have_next = j_next < p.per_queue;
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
         const Item tgtB = last ? nxt : cur;
         const int c0B = last_row ? (last_ch ? 0 : (ch + 1) * CK) : ch * CK;
         const int rowB = last_row ? 0 : row + 1;
-        if (ch == 0 && row == 0 && tid == 0) j_after = atomicAdd(p.queue + q, 1);
+        if (ch == 0 && row == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
         if (pfB && !(p.dbg & 1)) issue_B(tgtB, c0B, rowB, bbuf ^ 1);
         const bool pfA = last_row && pfB;                          // next chunk's pixels: loaded under the last tap row
         if (pfA && !(p.dbg & 1)) issue_A(tgtB, c0B);
@@ -1107,7 +1110,7 @@ static int ensure_attrs() {
                                                                     kVariants[i].pp ? 512 : 256, kVariants[i].lds));
         kVariants[i].occ = occ > 0 ? occ : 1;
     }
-    ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, 8 * sizeof(int)));
+    ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, QUEUE_INTS * sizeof(int)));
     g_attr_done = true;
     return ROMP_OK;
 }
@@ -1204,7 +1207,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.per_queue = (p.tiles_total / p.n_queues) * p.ns_total;
     if (queue == nullptr) {
         queue = g_queue_scratch;
-        ROMP_HIP_CHECK(hipMemsetAsync(queue, 0, 8 * sizeof(int), st));
+        ROMP_HIP_CHECK(hipMemsetAsync(queue, 0, QUEUE_INTS * sizeof(int), st));
     }
     p.queue = queue;
     const long items = (long)p.tiles_total * p.ns_total;

@@ -37,7 +37,7 @@ struct romp_net {
     std::vector<romp_op> ops;
     std::vector<int64_t> buf_floats;     // per image
     std::vector<float*> bufs;
-    int* queues = nullptr;               // 2 lanes x n_ops x 8 work counters, zeroed at the start of a forward
+    int* queues = nullptr;               // 2 lanes x n_ops x QUEUE_INTS work counters, zeroed at the start of a forward
     int max_batch = 0;
     int mode = 0;
     int use_graph = 0;
@@ -76,7 +76,7 @@ static float* resolve_out(romp_net* n, int buf, float* center, float* params, in
 static int run_op(romp_net* n, size_t idx, int variant, const float* image, int B, float* center, float* params,
                   hipStream_t st, int lane = 0, int b0 = 0) {
     const romp_op& op = n->ops[idx];
-    int* queue = n->queues + ((size_t)lane * n->ops.size() + idx) * 8;
+    int* queue = n->queues + ((size_t)lane * n->ops.size() + idx) * QUEUE_INTS;
     auto resolve_in = [&](romp_net* nn, int buf, const float* img) { return ::resolve_in(nn, buf, img, b0); };
     auto resolve_out = [&](romp_net* nn, int buf, float* c, float* p) { return ::resolve_out(nn, buf, c, p, b0); };
     switch (op.kind) {
@@ -153,7 +153,7 @@ static const std::vector<int>* tuned_for(romp_net* n, int B) {
 }
 
 static int reset_queues(romp_net* n, hipStream_t st) {
-    ROMP_HIP_CHECK(hipMemsetAsync(n->queues, 0, 2 * n->ops.size() * 8 * sizeof(int), st));
+    ROMP_HIP_CHECK(hipMemsetAsync(n->queues, 0, 2 * n->ops.size() * QUEUE_INTS * sizeof(int), st));
     return ROMP_OK;
 }
 
@@ -242,7 +242,7 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
         e = hipMemset(n->bufs[i], 0, bytes);
         if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); romp_net_destroy(n); return ROMP_EHIP; }
     }
-    if (hipMalloc((void**)&n->queues, (size_t)2 * n_ops * 8 * sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&n->queues, (size_t)2 * n_ops * QUEUE_INTS * sizeof(int)) != hipSuccess) {
         set_error("queue allocation failed");
         romp_net_destroy(n);
         return ROMP_ENOMEM;
