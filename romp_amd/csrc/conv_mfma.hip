@@ -926,9 +926,9 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
         const int c0B = last_row ? (last_ch ? 0 : (ch + 1) * CK) : ch * CK;
         const int rowB = last_row ? 0 : row + 1;
         if (ch == 0 && row == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
-        if (pfB && !(p.dbg & 1)) issue_B(tgtB, c0B, rowB, bbuf ^ 1);
+        if (pfB && !(p.dbg & (1 | 128))) issue_B(tgtB, c0B, rowB, bbuf ^ 1);
         const bool pfA = last_row && pfB;                          // next chunk's pixels: loaded under the last tap row
-        if (pfA && !(p.dbg & 1)) issue_A(tgtB, c0B);
+        if (pfA && !(p.dbg & (1 | 64))) issue_A(tgtB, c0B);
         if (!(p.dbg & 8)) {
             const char* sBc = sB + bbuf * (X::SUB_UNITS * 16);
 #pragma unroll
