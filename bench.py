@@ -49,6 +49,8 @@ def parse_args():
                     help='f32: exact f32 MFMA kernels only; bf16x3: also offer the f32-accurate bf16x3-split kernels to the autotuner')
     ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
+    ap.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
+                    help='resnet50: BASELINE configs[0]\'s model (the reference runs it on the CPU only) at the headline batch size')
     ap.add_argument('--split', type=int, default=1, help='2: run the batch as two half-batch lanes on two streams (convs capped at --wg-cap WG/CU)')
     ap.add_argument('--wg-cap', type=int, default=1)
     ap.add_argument('--tune-file', type=str, default=None,
@@ -267,8 +269,13 @@ def main():
         return bench_smpl(args, dev)
     settings = romp_amd.romp_settings([])
     settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
-    settings.conv_math = args.conv_math
-    sd = S.make_romp_state_dict(0)
+    settings.conv_math, settings.backbone = args.conv_math, args.backbone
+    if args.backbone == 'resnet50':
+        from oracle import resnet_oracle as RO          # seeded synthetic weights only (the generator lives with the oracle)
+        sd = RO.make_resnet_state_dict(0, center_bias=2.0)
+        args.no_cpu_baseline = True                      # the cpu_baseline leg times the HRNet-32 oracle
+    else:
+        sd = S.make_romp_state_dict(0)
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
     model.model.set_streams(args.streams)
@@ -320,13 +327,14 @@ def main():
         dt = float(t.item())
     total_images = B * world * args.steps
     result = {
-        'metric': 'images/sec (512x512, HRNet-32)', 'value': round(total_images / dt, 2), 'unit': 'images/s',
+        'metric': 'images/sec (512x512, %s)' % ('HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'), 'value': round(total_images / dt, 2), 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as bf16x3-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)',
         'data': 'synthetic',
-        'config': {'workload': 'ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); '
-                               'net+parse+SMPL%s' % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
+        'config': {'workload': (('ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); ' if args.backbone == 'hrnet32'
+                                 else 'ROMP ResNet-50 512x512 (BASELINE configs[0] model), batch=%d synthetic images per GPU; ') +
+                                'net+parse+SMPL%s') % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'persons_per_image': round(persons / (B * world), 2),
                    'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math, 'batch_lanes': args.split, 'parallelism': 'dp%d' % world},
     }

@@ -37,7 +37,7 @@ extern "C" {
 #define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
 #define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
 
-#define ROMP_ABI_VERSION 1
+#define ROMP_ABI_VERSION 2
 
 int         romp_abi_version(void);
 const char* romp_last_error(void);
@@ -63,6 +63,8 @@ const char* romp_last_error(void);
 #define ROMP_OP_BEV_PACK  6     /* in_buf maps_fv (B,128,128,4) + res_buf feats (..,16) -> out_buf (B,128,2560)   */
 #define ROMP_OP_BEV_MAPS  7     /* in_buf maps_fv, res_buf bv (B,128,128) -> out_buf center3d, term_buf[0] cam3d;
                                    weight = 64 scale anchors (get_cam3dmap_anchor, bev/model.py:77-87)          */
+#define ROMP_OP_STEM7     9     /* (x/255-mean)/std + conv7x7 s2 p3 (Cin=3) + BN + ReLU   (romp/lib/models/resnet_50.py:32-44,56) */
+#define ROMP_OP_MAXPOOL   10    /* MaxPool2d(3, 2, 1) on NHWC                             (resnet_50.py:45,56)                   */
 #define ROMP_OP_CONV3D    8     /* 3x3x3 conv Cin->Cin (1|3) on (B,C,64,128,128) + scale/shift (+res) (+ReLU)     */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
@@ -83,6 +85,10 @@ typedef struct romp_op {
     int32_t term_cstride[4];
     int32_t stream;               /* 0 = main stream, 1..3 = side stream (between FORK and JOIN):
                                      independent HRNet branches run concurrently (model.py:230-231) */
+    int32_t pad_h, pad_w;         /* CONV: zero rows / columns before the first tap; -1 = ksize/2 ('same' padding).
+                                     ksize 2 (one output parity of ConvTranspose2d k4 s2 p1): 1 or 0               */
+    int32_t out_rstride, out_bstride;  /* CONV: output row / image stride in floats; 0 = dense (Wo*out_cstride,
+                                     Ho*Wo*out_cstride).  Sparse strides interleave the parity outputs of a transposed conv */
     int32_t reserved;
     const float* weight;          /* packed [group][chunk][tap][cin/4][cout_pad][4]       */
     const float* scale;           /* [group][cout_pad]  gamma/sqrt(var+eps)  (or 1)       */

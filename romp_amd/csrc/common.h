@@ -41,6 +41,8 @@ int conv_num_variants();
 int conv_init();
 bool conv_variant_valid(const romp_op& op, int variant);
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
+int launch_stem7(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
+int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStream_t st);
 struct FuseTerm { const float* ptr; int shift; int cstride; };
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
                    int out_cstride, int out_coff, int relu, hipStream_t st);

@@ -51,6 +51,8 @@ struct ConvParams {
     int n_queues, per_queue;  // 8 (XCD-aware) or 1
     int vec_io;               // epilogue may use float4 loads/stores
     int w_gs;                 // floats per group in the packed weight
+    int pad_h, pad_w;         // rows / columns of zero padding before the first tap
+    int out_rs, out_bs;       // output row stride / image stride in floats (dense: Wo*out_cs, Ho*Wo*out_cs)
     int dbg;                  // ablation switches (ROMP_CONV_DEBUG; timing experiments only)
 };
 
@@ -58,11 +60,11 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 struct ConvCfg {
-    // KS = 1: 1x1, 3: 3x3, 13: 1x3 (Conv1d k=3 along W; rows of the "image" are independent sequences)
+    // KS = 1: 1x1, 2: 2x2 (one output parity of a ConvTranspose2d k4 s2), 3: 3x3, 13: 1x3 (Conv1d k=3 along W; rows of
+    // the "image" are independent sequences).  The zero padding before the first tap is a run-time parameter.
     static constexpr int KH = (KS == 13) ? 1 : KS;
     static constexpr int KW = (KS == 13) ? 3 : KS;
     static constexpr int TAPS = KH * KW;
-    static constexpr int PADH = KH / 2, PADW = KW / 2;
     static constexpr int RPB = 32 / TW;              // tile rows per 32-pixel block
     static constexpr int TH = 4 * MT * RPB;          // output tile rows
     static constexpr int HR = (TH - 1) * S + KH;     // haloed input rows
@@ -100,10 +102,10 @@ template <int KS, int S, int MT, int NT, int TW, int CK>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][NT],
                                               const float* sSc, int wave, int li, int lh) {
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
-    float* out = p.out + (size_t)cur.b * p.Ho * p.Wo * p.out_cs + p.out_co + cur.g * p.out_gs;
+    float* out = p.out + (size_t)cur.b * p.out_bs + p.out_co + cur.g * p.out_gs;
     const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
     const float floor_v = p.relu ? 0.f : -__builtin_inff();
-    unsigned pixo[MT];
+    unsigned pixo[MT], outo[MT];                     // residual pixel index; output offset (row / pixel strides may be sparse)
     bool rowok[MT];                                  // partial tiles along H (e.g. Conv1d over B < TH sequences)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -111,6 +113,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
         const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
         rowok[m] = oy < p.Ho;
         pixo[m] = rowok[m] ? (unsigned)(oy * p.Wo + ox) : 0u;
+        outo[m] = rowok[m] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
     }
     if (p.vec_io) {
         float4 r[MT][NT][4];
@@ -144,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                     v.y = fmaxf(fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y) + r[m][n][g4].y, floor_v);
                     v.z = fmaxf(fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z) + r[m][n][g4].z, floor_v);
                     v.w = fmaxf(fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w) + r[m][n][g4].w, floor_v);
-                    if (rowok[m]) *reinterpret_cast<float4*>(out + (pixo[m] * (unsigned)p.out_cs + (unsigned)(cur.n0 + cl))) = v;
+                    if (rowok[m]) *reinterpret_cast<float4*>(out + (outo[m] + (unsigned)(cur.n0 + cl))) = v;
                 }
             }
     } else {
@@ -162,7 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                         if (co + e < p.Cout && rowok[m]) {
                             float t = fmaf(acc[m][n][g4 * 4 + e], sSc[cl + e], sSc[C::NW + cl + e]);
                             if (res) t += res[pixo[m] * (unsigned)p.res_cs + (unsigned)(co + e)];
-                            out[pixo[m] * (unsigned)p.out_cs + (unsigned)(co + e)] = fmaxf(t, floor_v);
+                            out[outo[m] + (unsigned)(co + e)] = fmaxf(t, floor_v);
                         }
                     }
                 }
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     auto issue_loads = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
         const float* wg = p.w + (size_t)it.g * p.w_gs;
-        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
+        const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
     auto issue_loads = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
         const float* wg = p.w + (size_t)it.g * p.w_gs;
-        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
+        const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
     auto issue_loads = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
         const uint4* wg = p.w3 + (size_t)it.g * (C::TAPS * (p.cin_pad >> 4) * 6 * p.cout_pad);
-        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
+        const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
     };
     auto issue_A = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
-        const int iy0 = it.ty * C::TH * S - C::PADH, ix0 = it.tx * TW * S - C::PADW;
+        const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
             const int idx = tid + k * 256;
@@ -1009,7 +1012,7 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
         const int KH = KS == 13 ? 1 : KS, KW = KS == 13 ? 3 : KS;
         float acc = 0.f;
         for (int tap = 0; tap < KH * KW; ++tap) {
-            const int iy = oy * S - KH / 2 + tap / KW, ix = ox * S - KW / 2 + tap % KW;
+            const int iy = oy * S - p.pad_h + tap / KW, ix = ox * S - p.pad_w + tap % KW;
             if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
             const float* px = in + ((size_t)iy * p.W + ix) * p.in_cs;
             for (int c = 0; c < p.cin_valid; ++c)
@@ -1019,7 +1022,7 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
         const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
         if (p.res) v += p.res[pix * p.res_cs + p.res_co + g * p.res_gs + co];
         if (p.relu) v = fmaxf(v, 0.f);
-        p.out[pix * p.out_cs + p.out_co + g * p.out_gs + co] = v;
+        p.out[(size_t)b * p.out_bs + (size_t)oy * p.out_rs + (size_t)ox * p.out_cs + p.out_co + g * p.out_gs + co] = v;
     }
 }
 
@@ -1061,6 +1064,10 @@ static ConvVariant kVariants[] = {
     ROMP_CONV_VARIANT(1, 1, 1, 1, 16, 32), ROMP_CONV_VARIANT(1, 1, 1, 2, 16, 32),
     ROMP_CONV_VARIANT(1, 1, 2, 2, 16, 32),
     ROMP_CONV_VARIANT(1, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(1, 1, 2, 2, 32, 16),
+    // 1x1 stride 2 (ResNet-50 downsample branches) and 2x2 (the four output parities of ConvTranspose2d k4 s2 p1)
+    ROMP_CONV_VARIANT(1, 2, 1, 2, 16, 32), ROMP_CONV_VARIANT(1, 2, 1, 1, 16, 32), ROMP_CONV_VARIANT(1, 2, 2, 2, 16, 32),
+    ROMP_CONV_VARIANT(2, 1, 1, 2, 16, 16), ROMP_CONV_VARIANT(2, 1, 2, 2, 16, 16), ROMP_CONV_VARIANT(2, 1, 2, 2, 32, 16),
+    ROMP_CONV_VARIANT(2, 1, 1, 1, 16, 16),
     // 1x3 (Conv1d k=3: BEV bird's-eye-view head, bev/model.py:24-45,179-182)
     ROMP_CONV_VARIANT(13, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 1, 32, 16),
     ROMP_CONV_VARIANT(13, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT(13, 1, 1, 2, 32, 32),
@@ -1072,6 +1079,7 @@ static ConvVariant kVariants[] = {
     ROMP_CONV_VARIANT_BX3(3, 2, 1, 2, 16, 16), ROMP_CONV_VARIANT_BX3(3, 2, 1, 1, 16, 16), ROMP_CONV_VARIANT_BX3(3, 2, 1, 2, 32, 16),
     ROMP_CONV_VARIANT_BX3(1, 1, 2, 2, 32, 32), ROMP_CONV_VARIANT_BX3(1, 1, 2, 1, 32, 32), ROMP_CONV_VARIANT_BX3(1, 1, 1, 2, 16, 32),
     ROMP_CONV_VARIANT_BX3(1, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_BX3(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_BX3(13, 1, 2, 2, 32, 16),
+    ROMP_CONV_VARIANT_BX3(2, 1, 1, 2, 16, 16), ROMP_CONV_VARIANT_BX3(2, 1, 2, 2, 16, 16), ROMP_CONV_VARIANT_BX3(1, 1, 1, 2, 32, 32),
     // bf16x3 with LDS-DMA weight rows
     ROMP_CONV_VARIANT_BXD(3, 1, 2, 2, 16, 16), ROMP_CONV_VARIANT_BXD(3, 1, 2, 2, 32, 16),
     ROMP_CONV_VARIANT_BXD(3, 1, 2, 1, 16, 16), ROMP_CONV_VARIANT_BXD(3, 1, 2, 1, 32, 16),
@@ -1147,6 +1155,7 @@ static int choose_variant(const romp_op& op, int Ho, int Wo, int B) {
 
 static void out_dims(const romp_op& op, int* Ho, int* Wo) {
     const int kh = op.ksize == 13 ? 1 : op.ksize, kw = op.ksize == 13 ? 3 : op.ksize;
+    if (op.ksize == 2) { *Ho = op.H / op.stride; *Wo = op.W / op.stride; return; }   // 2x2: pad_h + (the other side) = 1 in total
     *Ho = (op.H + 2 * (kh / 2) - kh) / op.stride + 1;
     *Wo = (op.W + 2 * (kw / 2) - kw) / op.stride + 1;
 }
@@ -1161,7 +1170,7 @@ bool conv_variant_valid(const romp_op& op, int variant) {
 
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B, int mode,
                 int variant, int* queue, hipStream_t st, int wg_cap) {
-    ROMP_REQUIRE(op.ksize == 1 || op.ksize == 3 || op.ksize == 13, "conv: ksize %d unsupported", op.ksize);
+    ROMP_REQUIRE(op.ksize == 1 || op.ksize == 2 || op.ksize == 3 || op.ksize == 13, "conv: ksize %d unsupported", op.ksize);
     ROMP_REQUIRE(op.stride == 1 || op.stride == 2, "conv: stride %d unsupported", op.stride);
     ROMP_REQUIRE(op.groups >= 1, "conv: groups must be >= 1");
     ROMP_REQUIRE((op.in_cstride & 3) == 0 && (op.in_coff & 3) == 0 && (op.in_gstride & 3) == 0 && (op.Cin & 3) == 0,
@@ -1177,6 +1186,11 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.res_gs = op.res_gstride;
     p.relu = op.relu;
     p.w_gs = (op.ksize == 13 ? 3 : op.ksize * op.ksize) * op.cin_pad * op.cout_pad;
+    const int kh = op.ksize == 13 ? 1 : op.ksize, kw = op.ksize == 13 ? 3 : op.ksize;
+    p.pad_h = op.pad_h >= 0 ? op.pad_h : kh / 2;
+    p.pad_w = op.pad_w >= 0 ? op.pad_w : kw / 2;
+    p.out_rs = op.out_rstride > 0 ? op.out_rstride : p.Wo * op.out_cstride;
+    p.out_bs = op.out_bstride > 0 ? op.out_bstride : p.Ho * p.Wo * op.out_cstride;
     p.tiles_x = p.tiles_y = p.tiles_total = 1;
     p.nslices = p.ns_total = p.n_queues = p.per_queue = 1;
     p.queue = nullptr;

@@ -86,6 +86,18 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(in && out, "stem: bad buffers %d -> %d", op.in_buf, op.out_buf);
             return launch_stem(op, in, out, B, st);
         }
+        case ROMP_OP_STEM7: {
+            const float* in = resolve_in(n, op.in_buf, image);
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(in && out, "stem7: bad buffers %d -> %d", op.in_buf, op.out_buf);
+            return launch_stem7(op, in, out, B, st);
+        }
+        case ROMP_OP_MAXPOOL: {
+            const float* in = resolve_in(n, op.in_buf, image);
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(in && out, "maxpool: bad buffers %d -> %d", op.in_buf, op.out_buf);
+            return launch_maxpool(op, in, out, B, st);
+        }
         case ROMP_OP_BEV_PACK: {
             const float* fv = resolve_in(n, op.in_buf, image);
             const float* ft = resolve_in(n, op.res_buf, image);
@@ -474,6 +486,8 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     ROMP_REQUIRE(op && out && n > 0 && B > 0, "romp_conv_describe: bad arguments");
     if (op->kind == ROMP_OP_STEM) { snprintf(out, n, "stem_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FUSESUM) { snprintf(out, n, "fusesum"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_STEM7) { snprintf(out, n, "stem7_conv"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_MAXPOOL) { snprintf(out, n, "maxpool3s2"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BEV_PACK) { snprintf(out, n, "bev_pack"); return ROMP_OK; }

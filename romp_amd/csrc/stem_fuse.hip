@@ -85,6 +85,120 @@ int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStr
     return ROMP_OK;
 }
 
+// ---- ResNet-50 stem (romp/lib/models/resnet_50.py:32-38,41-44,56): ImageNet normalisation (x/255 - mean)/std fused
+// into the 3->64 7x7 stride-2 pad-3 convolution + BN + ReLU, then MaxPool2d(3, 2, 1).  Same VALU structure as the
+// 3x3 stem: a 16x16 output tile per workgroup, the 37x37x3 normalised halo and the 147x64 weights in LDS.
+struct Stem7Params {
+    const float* image; const float* w; const float* scale; const float* shift; float* out;
+    int H, W, Ho, Wo, out_cs, out_co, tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256) void stem7_conv_kernel(Stem7Params p) {
+    constexpr int T = 16, HS = 2 * T + 5;
+    __shared__ __attribute__((aligned(16))) float s_in[HS * HS * 3];
+    __shared__ __attribute__((aligned(16))) float s_w[147 * 64];
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x; bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const float* img = p.image + (size_t)b * p.H * p.W * 3;
+    const int iy0 = ty * T * 2 - 3, ix0 = tx * T * 2 - 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int idx = tid; idx < HS * HS * 3; idx += 256) {
+        const int c = idx % 3, hx = (idx / 3) % HS, hy = idx / (HS * 3);
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        float v = 0.f;                               // zero padding is applied AFTER normalisation
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            v = (img[((size_t)iy * p.W + ix) * 3 + c] / 255.0f - mean[c]) / stdv[c];
+        s_in[idx] = v;
+    }
+    for (int idx = tid; idx < 147 * 64; idx += 256) s_w[idx] = p.w[idx];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int cg = lane & 15, ps = lane >> 4;
+    float4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int dy = 0; dy < 7; ++dy)
+#pragma unroll 1
+        for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float4 w4 = *reinterpret_cast<const float4*>(s_w + ((dy * 7 + dx) * 3 + ci) * 64 + cg * 4);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int row = wave * 4 + (t >> 2), col = (t & 3) * 4 + ps;
+                    const float x = s_in[((row * 2 + dy) * HS + col * 2 + dx) * 3 + ci];
+                    acc[t].x = fmaf(x, w4.x, acc[t].x); acc[t].y = fmaf(x, w4.y, acc[t].y);
+                    acc[t].z = fmaf(x, w4.z, acc[t].z); acc[t].w = fmaf(x, w4.w, acc[t].w);
+                }
+            }
+    const float4 sc = *reinterpret_cast<const float4*>(p.scale + cg * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(p.shift + cg * 4);
+    float* out = p.out + (size_t)b * p.Ho * p.Wo * p.out_cs + p.out_co;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int oy = ty * T + wave * 4 + (t >> 2), ox = tx * T + (t & 3) * 4 + ps;
+        float4 v;
+        v.x = fmaxf(fmaf(acc[t].x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(acc[t].y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(acc[t].z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(acc[t].w, sc.w, sh.w), 0.f);
+        *reinterpret_cast<float4*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + cg * 4) = v;
+    }
+}
+
+int launch_stem7(const romp_op& op, const float* image, float* out, int B, hipStream_t st) {
+    ROMP_REQUIRE(op.Cin == 3 && op.Cout == 64 && op.ksize == 7 && op.stride == 2, "stem7: expects 3->64 k7 s2");
+    ROMP_REQUIRE(op.H % 32 == 0 && op.W % 32 == 0, "stem7: input %dx%d must be a multiple of 32", op.H, op.W);
+    ROMP_REQUIRE((op.out_cstride & 3) == 0 && (op.out_coff & 3) == 0, "stem7: output channels must be float4 aligned");
+    Stem7Params p;
+    p.image = image; p.w = op.weight; p.scale = op.scale; p.shift = op.shift; p.out = out;
+    p.H = op.H; p.W = op.W; p.Ho = op.H / 2; p.Wo = op.W / 2;
+    p.out_cs = op.out_cstride; p.out_co = op.out_coff;
+    p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 16;
+    hipLaunchKernelGGL(stem7_conv_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1) on NHWC float32 (padding = -inf, like torch)
+__global__ void maxpool3s2_kernel(const float* __restrict__ in, int H, int W, int C4, int in_cs, float* __restrict__ out, int out_cs,
+                                  size_t total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int c = (int)(r % C4) * 4; r /= C4;
+        const int x = (int)(r % Wo); r /= Wo;
+        const int y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float4 m = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int iy = 2 * y + dy, ix = 2 * x + dx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * H + iy) * W + ix) * in_cs + c);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+        *reinterpret_cast<float4*>(out + (((size_t)b * Ho + y) * Wo + x) * out_cs + c) = m;
+    }
+}
+
+int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStream_t st) {
+    ROMP_REQUIRE(in && out && (op.Cin & 3) == 0 && (op.in_cstride & 3) == 0 && (op.out_cstride & 3) == 0 && !(op.H & 1) && !(op.W & 1),
+                 "maxpool: bad shape");
+    const size_t total = (size_t)B * (op.H / 2) * (op.W / 2) * (op.Cin / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, op.H, op.W, op.Cin / 4, op.in_cstride, out,
+                       op.out_cstride, total);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
 struct FuseParams {
     const float* t[4]; int shift[4]; int cs[4];
     float* out; int n_terms, H, W, C4, out_cs, out_co, relu; size_t total;

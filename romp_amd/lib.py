@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libromp_hip.so')
 
+ABI_VERSION = 2          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
 OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN, OP_BEV_PACK, OP_BEV_MAPS, OP_CONV3D = 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -29,7 +30,8 @@ class RompOp(C.Structure):
         ('cin_pad', C.c_int32), ('cout_pad', C.c_int32),
         ('n_terms', C.c_int32),
         ('term_buf', C.c_int32 * 4), ('term_shift', C.c_int32 * 4), ('term_cstride', C.c_int32 * 4),
-        ('stream', C.c_int32), ('reserved', C.c_int32),
+        ('stream', C.c_int32), ('pad_h', C.c_int32), ('pad_w', C.c_int32), ('out_rstride', C.c_int32), ('out_bstride', C.c_int32),
+        ('reserved', C.c_int32),
         ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('weight_aux', C.c_void_p),
     ]
 
@@ -95,7 +97,7 @@ def load():
         fn = getattr(lib, name)      # raises AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.romp_abi_version() != 1:
+    if lib.romp_abi_version() != ABI_VERSION:
         raise RompHipError('libromp_hip.so ABI version mismatch')
     _lib = lib
     return lib

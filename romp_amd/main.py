@@ -54,6 +54,9 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--conv_math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
                         help='[romp_amd] f32: f32 MFMA kernels only; bf16x3 (default): also the f32-accurate 3-way bf16 split kernels on the '
                              'bf16 matrix pipe, chosen per layer by measurement the first time a batch size is seen')
+    parser.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
+                        help='[romp_amd] hrnet32: the simple_romp model (ROMP.pkl); resnet50: the training tree\'s ResNet-50 variant '
+                             '(romp/lib/models/resnet_50.py + romp_model.py state_dict)')
     parser.add_argument('--host_preprocess', action='store_true', help='[romp_amd] pad/resize on the host (cv2 / numpy) instead of the device kernel')
     args = parser.parse_args(input_args)
     if not torch.cuda.is_available():
@@ -90,7 +93,10 @@ class ROMP(nn.Module):
         """main.py:72-77: load the state_dict and bind it into the HIP network context."""
         if state_dict is None:
             state_dict = torch.load(self.settings.model_path, map_location='cpu')
-        self.model = RompNet(state_dict, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32),
+        builder = None
+        if getattr(self.settings, 'backbone', 'hrnet32') == 'resnet50':
+            from .resnet_plan import build_romp_resnet50 as builder
+        self.model = RompNet(state_dict, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32), builder=builder,
                              bf16x3=getattr(self.settings, 'conv_math', 'bf16x3') == 'bf16x3')
 
     def _initilization_(self, smpl_model=None):

@@ -40,9 +40,9 @@ class RompNet:
             self._h = h
             ms = input_size // 8
             self.out_shapes = out_shapes or ((ms, ms), (ms, ms, 145))
-            if builder is None:      # ROMP head: constant CoordConv channels of the head input (model.py:473)
+            if self.program.coord_off is not None:      # ROMP head: constant CoordConv channels of the head input (model.py:473)
                 fs = input_size // 4
-                coords = coord_channels(self.max_batch, fs, self.device)
+                coords = coord_channels(self.max_batch, fs, self.device, self.program.head_in_ch, self.program.coord_off)
                 L.check(self.lib.romp_net_write_buffer(self._h, self.program.head_in_buf, L.ptr(coords),
                                                        coords.numel(), L.stream_ptr(self.device)))
             torch.cuda.synchronize(self.device)

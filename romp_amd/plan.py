@@ -60,7 +60,7 @@ def conv_pads(cin, cout, ksize):
     cout to the 32-wide MFMA N-block (64 when the layer has >= 64 channels)."""
     if ksize == 1:
         ck = 32 if cin % 32 == 0 else 16
-    else:                                   # 3 (3x3) and 13 (1x3, Conv1d)
+    else:                                   # 3 (3x3), 2 (2x2) and 13 (1x3, Conv1d)
         ck = 16 if cin % 16 == 0 else 8
     return _round_up(cin, ck), _round_up(cout, 64 if cout >= 64 else 32)
 
@@ -113,6 +113,7 @@ class Program:
         self.bf16x3 = False                                    # also pack bf16x3-split weights (conv_bx3 kernels)
         self.persistent = set()
         self.head_in_buf: Optional[int] = None
+        self.head_in_ch, self.coord_off = HEAD_IN_CH, None     # coord_off: first of the two constant CoordConv channels
 
     # ---- buffers -------------------------------------------------------------------------
     def alloc(self, floats, persistent=False):
@@ -177,8 +178,11 @@ class Program:
 
     # ---- ops -----------------------------------------------------------------------------
     def conv(self, name, x: Act, w, scale, shift, ksize, stride, relu, res: Optional[Act] = None,
-             out: Optional[Act] = None, groups=1, out_buf_special=None, out_cstride=None, out_coff=0):
-        """w: list (per group) of OIHW tensors; scale/shift: list of per-group vectors."""
+             out: Optional[Act] = None, groups=1, out_buf_special=None, out_cstride=None, out_coff=0,
+             pad=(-1, -1), out_rstride=0, out_bstride=0):
+        """w: list (per group) of OIHW tensors; scale/shift: list of per-group vectors.  pad: zero rows / columns
+        before the first tap (-1: ksize//2); out_rstride / out_bstride: sparse output row / image strides (floats) for
+        the interleaved parity outputs of a transposed conv (`out` then is the full-resolution tensor)."""
         cout, cin = w[0].shape[0], w[0].shape[1]
         cin_phys = x.C // groups if groups > 1 else x.C      # channels the loader may touch
         cin_pad, cout_pad = conv_pads(cin_phys, cout, ksize)
@@ -193,8 +197,11 @@ class Program:
         if self.bf16x3 and cin_pad % 16 == 0:
             paux = self._dev(torch.stack([pack_conv_weight_bx3(wi, cin_pad, cout_pad) for wi in w]))
         kh, kw = (1, 3) if ksize == 13 else (ksize, ksize)
-        Ho = (x.H + 2 * (kh // 2) - kh) // stride + 1
-        Wo = (x.W + 2 * (kw // 2) - kw) // stride + 1
+        if ksize == 2:
+            Ho, Wo = x.H // stride, x.W // stride
+        else:
+            Ho = (x.H + 2 * (kh // 2) - kh) // stride + 1
+            Wo = (x.W + 2 * (kw // 2) - kw) // stride + 1
         if out is None and out_buf_special is None:
             out = self.new_act(cout * groups, Ho, Wo)
         op = RompOp()
@@ -210,6 +217,7 @@ class Program:
         if res is not None:
             op.res_cstride, op.res_coff, op.res_gstride = res.cstride, res.coff, (cout if groups > 1 else 0)
         op.cin_pad, op.cout_pad = cin_pad, cout_pad
+        op.pad_h, op.pad_w, op.out_rstride, op.out_bstride = int(pad[0]), int(pad[1]), int(out_rstride), int(out_bstride)
         op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
         if paux is not None:
             op.weight_aux = paux.data_ptr()
@@ -387,16 +395,22 @@ def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512, bf16
     build_hrnet32_backbone(P, sd, input_size, out_cstride=HEAD_IN_CH)
     fs = input_size // 4
     head_x = Act(P.head_in_buf, HEAD_IN_CH, fs, fs, HEAD_IN_CH)
+    P.head_in_ch, P.coord_off = HEAD_IN_CH, 32
+    build_romp_head(P, sd, head_x, 34)
+    return P
 
-    # ---- head (model.py:445-481): the three towers share their input; first conv runs as one
-    # 34->192 conv, the BasicBlocks as 3-group convs, then three 1x1 output convs.
+
+def build_romp_head(P: Program, sd, head_x: Act, cin: int):
+    """The three head towers (model.py:445-481; training tree romp_model.py:78-103) on `head_x`, whose first `cin`
+    channels are [backbone features | 2 CoordConv maps]: the towers share their input, so the first conv runs as one
+    cin->192 conv, the BasicBlocks as 3-group convs, then three 1x1 output convs into the caller's tensors."""
     heads = (1, 2, 3)                                            # params(142), center(1), cam(3)
     w0, s0, b0 = [], [], []
     for h in heads:
         p = f'final_layers.{h}.0.'
         w = sd[p + '0.weight']
-        wp = torch.zeros(64, HEAD_IN_CH, 3, 3)
-        wp[:, :34] = w
+        wp = torch.zeros(64, head_x.cstride, 3, 3)
+        wp[:, :cin] = w
         s, b = fold_bn(sd, p + '1', 64, sd[p + '0.bias'])
         w0.append(wp); s0.append(s); b0.append(b)
     t = P.conv('head.conv0', head_x, [torch.cat(w0, 0)], [torch.cat(s0)], [torch.cat(b0)], 3, 2, True)
@@ -422,14 +436,13 @@ def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512, bf16
             P.conv('head.params' if h == 1 else 'head.cam', xin, [w], [s], [b], 1, 1, False,
                    out_buf_special=BUF_PARAMS, out_cstride=145, out_coff=3 if h == 1 else 0)
     P.free(t)
-    return P
 
 
-def coord_channels(max_batch, size, device):
-    """Initial content of the head input buffer: CoordConv maps in channels 32,33
+def coord_channels(max_batch, size, device, n_ch=HEAD_IN_CH, off=32):
+    """Initial content of the head input buffer: CoordConv maps in channels off, off+1
     (get_coord_maps model.py:8-37: ch0 varies along W, ch1 along H), zeros elsewhere."""
     r = torch.arange(size, dtype=torch.float32) / (size - 1) * 2 - 1
-    buf = torch.zeros(max_batch, size, size, HEAD_IN_CH)
-    buf[..., 32] = r.view(1, 1, size)
-    buf[..., 33] = r.view(1, size, 1)
+    buf = torch.zeros(max_batch, size, size, n_ch)
+    buf[..., off] = r.view(1, 1, size)
+    buf[..., off + 1] = r.view(1, size, 1)
     return buf.to(device)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), 'libromp_hip.so does not export %s' % n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert h.romp_abi_version() == 1
+    assert h.romp_abi_version() == L.ABI_VERSION == 2
 
 
 def test_romp_op_struct_layout_matches_header():
@@ -216,3 +216,18 @@ def test_shard_range_partitions():
         for a, b in zip(spans, spans[1:]):
             assert a[1] == b[0]
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_resnet50_plan_inventory():
+    """ROMP ResNet-50 lowered on the CPU: 74 ops, 53.9 GFLOP / image (SURVEY.md §8a totals: backbone 49.1 + head), each
+    transposed conv as four 2x2 parity convs with interleaving output strides."""
+    from oracle import resnet_oracle as RO
+    from romp_amd.resnet_plan import build_romp_resnet50
+    P = build_romp_resnet50(RO.make_resnet_state_dict(0), 'cpu')
+    assert len(P.ops) == 74
+    assert abs(sum(P.flops) / 1e9 - 53.88) < 0.05
+    dec = [(n, o) for n, o in zip(P.names, P.ops) if n.startswith('deconv')]
+    assert len(dec) == 12 and all(o.ksize == 2 and o.stride == 1 and o.out_rstride > 0 and o.out_bstride > 0 for _, o in dec)
+    assert sorted((o.pad_h, o.pad_w) for _, o in dec[:4]) == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    assert all(o.pad_h == -1 and o.pad_w == -1 for n, o in zip(P.names, P.ops) if o.kind == 2 and not n.startswith('deconv'))
+    assert P.coord_off == 64 and P.head_in_ch == 72
