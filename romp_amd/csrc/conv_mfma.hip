@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     int j_cur = j_cur0;
 
     float4 ra[C::NA], rb[C::NB];
+    unsigned ra_ok = 0;                                // bit k: ra[k] is a real (in-image, in-tile) load
     float rs = 0.f;                                    // one scale-or-shift value (threads < 2*NW)
 
     auto issue_loads = [&](const Item& it, int c0) {
@@ -246,16 +247,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
+            // BRANCH-FREE: an out-of-image / out-of-tile lane loads the tensor's first float4 instead and is zeroed when
+            // the stage is written to LDS.  With `if (ok) v = load` hipcc waits (vmcnt(0)) inside every conditional block,
+            // i.e. the tile arrives as NA serialized HBM round trips BEFORE the MFMA loop instead of underneath it.
             const int idx = tid + k * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < C::A_VEC) {
-                const int qq = idx % C::QC, pix = idx / C::QC;
-                const int hx = pix % C::HC, hy = pix / C::HC;
-                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
-                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
-            }
-            ra[k] = v;
+            const int idc = idx < C::A_VEC ? idx : 0;
+            const int qq = idc % C::QC, pix = idc / C::QC;
+            const int hx = pix % C::HC, hy = pix / C::HC;
+            const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid;
+            ra[k] = ldg4(in + (ok ? (unsigned)((iy * p.W + ix) * p.in_cs + c) : 0u));
+            ra_ok = k == 0 ? (ok ? 1u : 0u) : (ra_ok | ((ok ? 1u : 0u) << k));
         }
 #pragma unroll
         for (int k = 0; k < C::NB; ++k) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             const int idx = tid + k * 256;
             if (idx < C::A_VEC) {
                 const int qq = idx % C::QC, pix = idx / C::QC;
-                *reinterpret_cast<float4*>(sA + pix * C::PS + qq * 4) = ra[k];
+                *reinterpret_cast<float4*>(sA + pix * C::PS + qq * 4) = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
     if (done && tid == 0) sQ[2] = 1;
 
     float4 ra[C::NA], rb[C::NB];
+    unsigned ra_ok = 0;                                // bit k: ra[k] is a real (in-image, in-tile) load
     float rs = 0.f;
 
     auto issue_loads = [&](const Item& it, int c0) {
@@ -408,16 +411,17 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
         const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
+            // BRANCH-FREE: an out-of-image / out-of-tile lane loads the tensor's first float4 instead and is zeroed when
+            // the stage is written to LDS.  With `if (ok) v = load` hipcc waits (vmcnt(0)) inside every conditional block,
+            // i.e. the tile arrives as NA serialized HBM round trips BEFORE the MFMA loop instead of underneath it.
             const int idx = tid + k * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < C::A_VEC) {
-                const int qq = idx % C::QC, pix = idx / C::QC;
-                const int hx = pix % C::HC, hy = pix / C::HC;
-                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
-                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
-            }
-            ra[k] = v;
+            const int idc = idx < C::A_VEC ? idx : 0;
+            const int qq = idc % C::QC, pix = idc / C::QC;
+            const int hx = pix % C::HC, hy = pix / C::HC;
+            const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid;
+            ra[k] = ldg4(in + (ok ? (unsigned)((iy * p.W + ix) * p.in_cs + c) : 0u));
+            ra_ok = k == 0 ? (ok ? 1u : 0u) : (ra_ok | ((ok ? 1u : 0u) << k));
         }
 #pragma unroll
         for (int k = 0; k < C::NB; ++k) {
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
             const int idx = tid + k * 256;
             if (idx < C::A_VEC) {
                 const int qq = idx % C::QC, pix = idx / C::QC;
-                *reinterpret_cast<float4*>(sA + pix * C::PS + qq * 4) = ra[k];
+                *reinterpret_cast<float4*>(sA + pix * C::PS + qq * 4) = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
     int j_cur = j_cur0;
 
     float4 ra[C::NA];
+    unsigned ra_ok = 0;
     uint4 rb[X::NB];
     float rs = 0.f;
 
@@ -643,16 +648,17 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
         const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
+            // BRANCH-FREE: an out-of-image / out-of-tile lane loads the tensor's first float4 instead and is zeroed when
+            // the stage is written to LDS.  With `if (ok) v = load` hipcc waits (vmcnt(0)) inside every conditional block,
+            // i.e. the tile arrives as NA serialized HBM round trips BEFORE the MFMA loop instead of underneath it.
             const int idx = tid + k * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < C::A_VEC) {
-                const int qq = idx % C::QC, pix = idx / C::QC;
-                const int hx = pix % C::HC, hy = pix / C::HC;
-                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
-                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
-            }
-            ra[k] = v;
+            const int idc = idx < C::A_VEC ? idx : 0;
+            const int qq = idc % C::QC, pix = idc / C::QC;
+            const int hx = pix % C::HC, hy = pix / C::HC;
+            const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid;
+            ra[k] = ldg4(in + (ok ? (unsigned)((iy * p.W + ix) * p.in_cs + c) : 0u));
+            ra_ok = k == 0 ? (ok ? 1u : 0u) : (ra_ok | ((ok ? 1u : 0u) << k));
         }
 #pragma unroll
         for (int k = 0; k < X::NB; ++k) {
@@ -683,10 +689,11 @@ __global__ __launch_bounds__(256, 2) void conv_bx3_kernel(ConvParams p) {
             if (idx < C::A_VEC) {
                 const int qq = idx % C::QC, pix = idx / C::QC;
                 unsigned short h[4][3];
-                split3(ra[k].x, h[0][0], h[0][1], h[0][2]);
-                split3(ra[k].y, h[1][0], h[1][1], h[1][2]);
-                split3(ra[k].z, h[2][0], h[2][1], h[2][2]);
-                split3(ra[k].w, h[3][0], h[3][1], h[3][2]);
+                const float4 av = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                split3(av.x, h[0][0], h[0][1], h[0][2]);
+                split3(av.y, h[1][0], h[1][1], h[1][2]);
+                split3(av.z, h[2][0], h[2][1], h[2][2]);
+                split3(av.w, h[3][0], h[3][1], h[3][2]);
                 char* dst = sA + pix * X::PSB + qq * 8;
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
@@ -822,6 +829,7 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
     int j_cur = j_cur0;
 
     float4 ra[C::NA];
+    unsigned ra_ok = 0;
     float rs = 0.f;
 
     // LDS-DMA of the weight units of tap row `row`, channel chunk c0, into buffer `buf`
@@ -848,16 +856,17 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
         const int iy0 = it.ty * C::TH * S - p.pad_h, ix0 = it.tx * TW * S - p.pad_w;
 #pragma unroll
         for (int k = 0; k < C::NA; ++k) {
+            // BRANCH-FREE: an out-of-image / out-of-tile lane loads the tensor's first float4 instead and is zeroed when
+            // the stage is written to LDS.  With `if (ok) v = load` hipcc waits (vmcnt(0)) inside every conditional block,
+            // i.e. the tile arrives as NA serialized HBM round trips BEFORE the MFMA loop instead of underneath it.
             const int idx = tid + k * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < C::A_VEC) {
-                const int qq = idx % C::QC, pix = idx / C::QC;
-                const int hx = pix % C::HC, hy = pix / C::HC;
-                const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid)
-                    v = ldg4(in + (unsigned)((iy * p.W + ix) * p.in_cs + c));
-            }
-            ra[k] = v;
+            const int idc = idx < C::A_VEC ? idx : 0;
+            const int qq = idc % C::QC, pix = idc / C::QC;
+            const int hx = pix % C::HC, hy = pix / C::HC;
+            const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
+            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid;
+            ra[k] = ldg4(in + (ok ? (unsigned)((iy * p.W + ix) * p.in_cs + c) : 0u));
+            ra_ok = k == 0 ? (ok ? 1u : 0u) : (ra_ok | ((ok ? 1u : 0u) << k));
         }
         if (c0 == 0 && tid < 2 * C::NW) {
             const float* src = tid < C::NW ? p.scale : p.shift;
@@ -871,10 +880,11 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
             if (idx < C::A_VEC) {
                 const int qq = idx % C::QC, pix = idx / C::QC;
                 unsigned short h[4][3];
-                split3(ra[k].x, h[0][0], h[0][1], h[0][2]);
-                split3(ra[k].y, h[1][0], h[1][1], h[1][2]);
-                split3(ra[k].z, h[2][0], h[2][1], h[2][2]);
-                split3(ra[k].w, h[3][0], h[3][1], h[3][2]);
+                const float4 av = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                split3(av.x, h[0][0], h[0][1], h[0][2]);
+                split3(av.y, h[1][0], h[1][1], h[1][2]);
+                split3(av.z, h[2][0], h[2][1], h[2][2]);
+                split3(av.w, h[3][0], h[3][1], h[3][2]);
                 char* dst = sA + pix * X::PSB + qq * 8;
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {

@@ -53,7 +53,7 @@ if __name__ == '__main__':
         sys.exit(0)
     kind = os.environ.get('ABLATE_KIND', 'mfma')
     cases = [((64, 64, 3, 1, 64, True), [kind + '_k3s1_mt2_nt2_tw16', kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt1_nt2_tw16']),
-             ((32, 32, 3, 1, 128, True), [kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt2_nt1_tw32', kind + '_k3s1_mt1_nt1_tw32'])]
+             ((32, 32, 3, 1, 128, True), [kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt2_nt1_tw32', kind + '_k3s1_mt1_nt1_tw32', kind + '_k3s1_mt1_nt1_tw16'])]
     for case, variants in cases:
         print('case', case)
         for dbg in [int(x) for x in os.environ.get('ABLATE_DBG', '0,4,1,2,3,7,16,23,8,12').split(',')]:
