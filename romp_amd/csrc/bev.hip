@@ -90,16 +90,26 @@ __global__ __launch_bounds__(256) void conv3d_kernel(Conv3dParams p, int B) {
     __syncthreads();
     auto load_slice = [&](int d, int slot) {                     // slice d (may be outside: zeros), rows h0-1 .. h0+T3_H
         float* dst = ring + slot * SLICE;
-        for (int i = tid; i < C * (T3_H + 2) * (BM / 4); i += 256) {
-            const int q = i % (BM / 4);
-            int r = i / (BM / 4);
-            const int row = r % (T3_H + 2);
-            const int ci = r / (T3_H + 2);
+        constexpr int NE = C * (T3_H + 2) * (BM / 4), NL = (NE + 255) / 256;
+        float4 raw[NL];                                          // branch-free, all loads of the slice in flight together
+        bool ok[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = min(tid + k * 256, NE - 1);
+            const int q = i % (BM / 4), r = i / (BM / 4);
+            const int row = r % (T3_H + 2), ci = r / (T3_H + 2);
             const int h = h0 - 1 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)d < (unsigned)BD && (unsigned)h < (unsigned)BM)
-                v = *reinterpret_cast<const float4*>(inb + (size_t)ci * BVOX + ((size_t)d * BM + h) * BM + q * 4);
-            *reinterpret_cast<float4*>(dst + (ci * (T3_H + 2) + row) * T3_RW + 4 + q * 4) = v;
+            ok[k] = (unsigned)d < (unsigned)BD && (unsigned)h < (unsigned)BM;
+            raw[k] = *reinterpret_cast<const float4*>(inb + (ok[k] ? (size_t)ci * BVOX + ((size_t)d * BM + h) * BM + q * 4 : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = tid + k * 256;
+            if (i < NE) {
+                const int q = i % (BM / 4), r = i / (BM / 4);
+                const int row = r % (T3_H + 2), ci = r / (T3_H + 2);
+                *reinterpret_cast<float4*>(dst + (ci * (T3_H + 2) + row) * T3_RW + 4 + q * 4) = ok[k] ? raw[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     load_slice(d0 - 1, 0);

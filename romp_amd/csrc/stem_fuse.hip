@@ -27,15 +27,29 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     const int b = bx / p.tiles_y;
     const float* img = p.image + (size_t)b * p.H * p.W * 3;
     const int iy0 = ty * T * 2 - 1, ix0 = tx * T * 2 - 1;
-    for (int idx = tid; idx < HS * HS * 3; idx += 256) {
-        const int e = idx % (HS * 3), hy = idx / (HS * 3);
-        const int iy = iy0 + hy, ix = ix0 + e / 3;
-        float v = 0.f;                               // zero padding is applied AFTER normalisation
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            v = (img[((size_t)iy * p.W + ix0) * 3 + e] / 255.0f) * 2.0f - 1.0f;
-        s_in[idx] = v;
+    {   // halo fill, branch-free and batched: all loads of a thread are in flight together (a conditional load makes
+        // hipcc wait inside the branch: 13 serialized round trips per thread, which had this kernel at 0.54 ms)
+        constexpr int NL = (HS * HS * 3 + 255) / 256;
+        float raw[NL];
+        bool ok[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;
+            const int idc = idx < HS * HS * 3 ? idx : 0;
+            const int e = idc % (HS * 3), hy = idc / (HS * 3);
+            const int iy = iy0 + hy, ix = ix0 + e / 3;
+            ok[k] = idx < HS * HS * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            raw[k] = img[ok[k] ? ((size_t)iy * p.W + ix0) * 3 + e : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;               // zero padding is applied AFTER normalisation
+            if (idx < HS * HS * 3) s_in[idx] = ok[k] ? (raw[k] / 255.0f) * 2.0f - 1.0f : 0.f;
+        }
     }
-    for (int idx = tid; idx < 27 * 64; idx += 256) s_w[idx] = p.w[idx];
+#pragma unroll
+    for (int k = 0; k < (27 * 64 + 255) / 256; ++k)
+        if (tid + k * 256 < 27 * 64) s_w[tid + k * 256] = p.w[tid + k * 256];
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -105,15 +119,29 @@ __global__ __launch_bounds__(256) void stem7_conv_kernel(Stem7Params p) {
     const float* img = p.image + (size_t)b * p.H * p.W * 3;
     const int iy0 = ty * T * 2 - 3, ix0 = tx * T * 2 - 3;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-    for (int idx = tid; idx < HS * HS * 3; idx += 256) {
-        const int c = idx % 3, hx = (idx / 3) % HS, hy = idx / (HS * 3);
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        float v = 0.f;                               // zero padding is applied AFTER normalisation
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            v = (img[((size_t)iy * p.W + ix) * 3 + c] / 255.0f - mean[c]) / stdv[c];
-        s_in[idx] = v;
+    {   // halo fill, branch-free and batched (see stem_conv_kernel)
+        constexpr int NL = (HS * HS * 3 + 255) / 256;
+        float raw[NL];
+        bool ok[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;
+            const int idc = idx < HS * HS * 3 ? idx : 0;
+            const int c = idc % 3, hx = (idc / 3) % HS, hy = idc / (HS * 3);
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            ok[k] = idx < HS * HS * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            raw[k] = img[ok[k] ? ((size_t)iy * p.W + ix) * 3 + c : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;               // zero padding is applied AFTER normalisation
+            const int c = idx % 3;
+            if (idx < HS * HS * 3) s_in[idx] = ok[k] ? (raw[k] / 255.0f - mean[c]) / stdv[c] : 0.f;
+        }
     }
-    for (int idx = tid; idx < 147 * 64; idx += 256) s_w[idx] = p.w[idx];
+#pragma unroll
+    for (int k = 0; k < (147 * 64 + 255) / 256; ++k)
+        if (tid + k * 256 < 147 * 64) s_w[tid + k * 256] = p.w[tid + k * 256];
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     const int cg = lane & 15, ps = lane >> 4;
