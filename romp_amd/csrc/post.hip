@@ -40,11 +40,11 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ src, int H, 
         const int py = min(max(sy - 1 + a, 0), side - 1) - top;          // replicated border of the PADDED image
         for (int b = 0; b < 4; ++b) {
             const int px = min(max(sx - 1 + b, 0), side - 1) - left;
-            if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-                const unsigned char* p = src + ((size_t)py * W + px) * 3;
-                const float wgt = cy[a] * cx[b];
-                acc[0] += wgt * p[2]; acc[1] += wgt * p[1]; acc[2] += wgt * p[0];   // BGR -> RGB
-            }
+            // branch-free (taps in the zero padding read pixel 0 with weight 0): all 48 byte loads of a thread in flight
+            const bool ok = (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
+            const unsigned char* p = src + (ok ? ((size_t)py * W + px) * 3 : 0);
+            const float wgt = ok ? cy[a] * cx[b] : 0.f;
+            acc[0] += wgt * p[2]; acc[1] += wgt * p[1]; acc[2] += wgt * p[0];       // BGR -> RGB
         }
     }
     for (int c = 0; c < 3; ++c) dst[(size_t)i * 3 + c] = fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);
