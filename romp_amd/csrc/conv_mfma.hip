@@ -942,6 +942,7 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
         if (pfB && !(p.dbg & (1 | 128))) issue_B(tgtB, c0B, rowB, bbuf ^ 1);
         const bool pfA = last_row && pfB;                          // next chunk's pixels: loaded under the last tap row
         if (pfA && !(p.dbg & (1 | 64))) issue_A(tgtB, c0B);
+        __builtin_amdgcn_sched_barrier(0);               // keep every DMA / load issue ABOVE the MFMA block (hipcc sank 3 of the 5 DMAs below it)
         if (!(p.dbg & 8)) {
             const char* sBc = sB + bbuf * (X::SUB_UNITS * 16);
 #pragma unroll
