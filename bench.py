@@ -87,7 +87,7 @@ def roofline_report(model, images, lib, L):
     # `achieved` counts ALGORITHMIC flops (2*M*N*K of the f32 convolution).  A bf16x3 kernel issues six
     # bf16 MFMA products per algorithmic product, so its roof is the bf16 dense peak / 6; the f32 kernels
     # are priced against the f32 MFMA peak.
-    bx3 = 'bx3' in name
+    bx3 = 'conv_bx' in name                  # conv_bx3_* and conv_bxd_*: the bf16x3-split kernels
     peak = PEAK_BF16_MFMA_TFLOPS / BX3_PRODUCTS if bx3 else PEAK_F32_MFMA_TFLOPS
     roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                 frac=round(achieved / peak, 4), traffic=None,
