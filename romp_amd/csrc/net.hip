@@ -315,6 +315,13 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     hipStream_t st = (hipStream_t)stream;
     if (!n->use_graph || n->mode != 0) return run_all(n, image, B, center, params, st);
     ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
+    if (n->graphs.size() >= 32 && !n->graphs.count(GraphKey{B, image, center, params, lanes_active(n, B) ? 0 : -1})) {
+        // a caller that hands over new tensors every call must not grow the cache for ever
+        ROMP_HIP_CHECK(hipStreamSynchronize(st));
+        ROMP_HIP_CHECK(hipStreamSynchronize(n->lane_main));
+        for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
+        n->graphs.clear();
+    }
     auto capture = [&](hipStream_t origin, const GraphKey& key, auto&& body) -> int {
         if (n->graphs.count(key)) return ROMP_OK;
         hipGraph_t g = nullptr;

@@ -415,3 +415,20 @@ def test_forward_batch_matches_oracle(dev):
     ev = np.abs(out['verts'].cpu().numpy() - vo).max()
     print('end-to-end verts max-abs vs oracle pipeline', ev, 'persons', len(ref['batch_ids']))
     assert ev < 1e-3
+
+
+def test_graph_cache_is_bounded(dev):
+    """Graph mode with fresh output tensors on every call: the per-(batch, pointers) hipGraph cache must stay
+    bounded (it is dropped and rebuilt past 32 entries) and keep producing the same maps."""
+    from romp_amd.net import RompNet
+    net = RompNet(O.make_romp_state_dict(0), dev, max_batch=1, use_graph=True)
+    x = O.make_images(1, seed=1).to(dev)
+    s = torch.cuda.Stream()
+    keep = []
+    with torch.cuda.stream(s):
+        c0, p0 = net.forward_nhwc(x)
+        for _ in range(40):
+            c, p = net.forward_nhwc(x)
+            keep.append((c, p))                      # keep them alive: every call sees new pointers
+        s.synchronize()
+    assert all(torch.equal(c, c0) and torch.equal(p, p0) for c, p in keep)
