@@ -98,7 +98,36 @@ def roofline_report(model, images, lib, L):
                 flops_per_launch=a['flops'] / a['launches'], alg_bytes_per_launch=a['bytes'] / a['launches'],
                 hbm_gbs=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1), hbm_frac=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                 net_ms_per_batch=round(sum(ms), 3))
+    t = pmc_traffic(name, os.path.join(ROOT, 'profiles'))
+    if t is not None:                        # measured in a separate rocprofv3 --pmc pass of this command (profiles/README.md)
+        roof['traffic'] = round(t['bytes'])
+        roof['traffic_source'] = 'profiles/r01_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % t['kernel']
+        roof['traffic_over_algorithmic'] = round(t['bytes'] / (a['bytes'] / a['launches']), 3)
     return roof, classes
+
+
+def pmc_traffic(variant_name, pmc_dir):
+    """HBM bytes per launch of the kernel behind `variant_name` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv, produced by scripts/gpu_profile.sh: separate --pmc passes of
+    this same command; unit KiB per dispatch; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).
+    None if the files or the kernel are missing -- PMC counters cannot be read from inside this process."""
+    import csv
+    import re
+    m = re.match(r'conv_(mfma|pp|bx3|bxd)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    if not m:
+        return None
+    kern = 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % m.groups()
+    vals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        path = os.path.join(pmc_dir, 'r01_pmc_%s_by_kernel.csv' % counter)
+        if not os.path.exists(path):
+            return None
+        for row in csv.DictReader(open(path)):
+            if kern in row['kernel']:
+                vals[counter] = float(row[counter + '_mean']) * 1024.0
+    if len(vals) != 2:
+        return None
+    return dict(bytes=2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'], kernel=kern)
 
 
 def usable_cores():
