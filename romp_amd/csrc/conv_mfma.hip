@@ -53,7 +53,10 @@ struct ConvParams {
     int w_gs;                 // floats per group in the packed weight
     int pad_h, pad_w;         // rows / columns of zero padding before the first tap
     int out_rs, out_bs;       // output row stride / image stride in floats (dense: Wo*out_cs, Ho*Wo*out_cs)
-    int dbg;                  // ablation switches (ROMP_CONV_DEBUG; timing experiments only)
+    int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
+                              // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
+                              // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
+                              // only the pixel loads / only the weight DMA.  scripts/conv_ablate.py and DESIGN.md §4 use them.
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }

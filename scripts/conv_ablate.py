@@ -1,5 +1,6 @@
 """Ablation timing of one conv layer (GPU): which part of the kernel costs what.
-usage: python scripts/conv_ablate.py  (prints a table; outputs are wrong under dbg flags)"""
+usage: [ABLATE_KIND=mfma|bx3|bxd] [ABLATE_B=32] [ABLATE_DBG=0,4,...] python scripts/conv_ablate.py
+(prints a table; outputs are wrong under dbg flags -- bit meanings: ConvParams::dbg in csrc/conv_mfma.hip)"""
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
