@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-f32-companion', action='store_true', help='skip the extra conv_math=f32 timing of the same workload')
     ap.add_argument('--with-verts', type=int, default=0, help='N>1: also all-gather the 6890x3 vertices')
     return ap.parse_args()
 
@@ -373,6 +374,30 @@ def main():
                 roof, classes = roofline_report(model, images, lib, L)
             result['roofline'] = roof
             result['kernel_classes'] = classes
+        if world == 1 and args.conv_math == 'bf16x3' and args.backbone == 'hrnet32' and not args.no_f32_companion:
+            # the same workload with every conv on the exact-f32 MFMA kernels only, for readers who do not accept the
+            # bf16x3 split as float32 arithmetic (it passes the same 1e-4 gate): same steps, same timing discipline
+            del model
+            settings.conv_math = 'f32'
+            m32 = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+            m32.model.set_streams(args.streams)
+            if args.autotune:
+                m32.model.autotune(B)
+            if args.graph:
+                m32.model.set_graph(True)
+            with torch.cuda.stream(stream):
+                for _ in range(args.warmup):
+                    m32.forward_batch(images)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    m32.forward_batch(images)
+                torch.cuda.synchronize(dev)
+                dt32 = time.perf_counter() - t0
+            result['f32_mfma_companion'] = {'value': round(B * args.steps / dt32, 2), 'unit': 'images/s', 'dtype': 'f32',
+                                            'ms_per_step': round(dt32 / args.steps * 1e3, 3),
+                                            'note': 'same workload, conv_math=f32 (v_mfma_f32_32x32x2_f32 only)'}
+            del m32
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(sd, smpl_model, args.center_thresh, args.cpu_seconds)
         print(json.dumps(result), flush=True)

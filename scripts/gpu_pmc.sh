@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 COUNTERS="$1"; shift
 TAG=$(echo $COUNTERS | tr ' ' '_' | cut -c1-60)
 rm -rf /tmp/rp_pmc
-timeout 900 rocprofv3 --kernel-trace --pmc $COUNTERS --output-format csv -d /tmp/rp_pmc -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-roofline --steps 1 --warmup 1 "$@" > "$OUT/run_$TAG.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc $COUNTERS --output-format csv -d /tmp/rp_pmc -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-roofline --steps 1 --warmup 1 "$@" > "$OUT/run_$TAG.log" 2>&1
 echo "pmc exit $?"
 f=$(find /tmp/rp_pmc -name "*counter_collection.csv" | head -1)
 python - "$f" $COUNTERS > "$OUT/by_kernel_$TAG.csv" <<'PY'

@@ -10,7 +10,7 @@ export PYTHONUNBUFFERED=1
 # (no autotune measuring launches); ${BENCH_ARGS} e.g. "--conv-math f32" or "--workload bev"
 TUNE=/tmp/romp_tune.json
 rm -f $TUNE
-BENCH="python $REPO/bench.py --no-cpu-baseline --tune-file $TUNE ${BENCH_ARGS}"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --tune-file $TUNE ${BENCH_ARGS}"
 $BENCH --steps 2 --warmup 1 --no-roofline > "$OUT/bench_plain.log" 2>&1
 echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
