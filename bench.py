@@ -245,17 +245,25 @@ def bench_smpl(args, dev):
 def bench_bev(args, dev):
     """BASELINE configs[3]: BEV HRNet-32 + bird's-eye-view head, 512x512, batch 32, 1 GPU (not the headline line)."""
     from romp_amd import bev, synthetic as S
-    from oracle import bev_oracle as BO          # synthetic BEV weights only (generator lives with the oracle)
     s = bev.bev_settings([])
     s.GPU, s.max_batch, s.conv_math = dev.index or 0, args.batch, args.conv_math
-    sd = BO.make_bev_state_dict(0)
+    sd = S.make_bev_state_dict(0)
     model = bev.BEV(s, state_dict=sd, smpla_model=S.make_smpl_model(0, 11), smil_model=S.make_smpl_model(5, 10))
     images = S.make_images(args.batch, seed=4, device=dev)
-    # threshold giving ~12 persons per image on this synthetic input (cf. tests/golden/bev_b1.npz)
-    model.model.centermap_parser.conf_thresh = 0.6237
     if args.autotune:
         model.model.net.autotune(args.batch)
     pads = torch.tensor([[0., 512., 0., 512., 512., 512.]]).repeat(args.batch, 1)
+    # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
+    # ~12 persons per image, the load the ROMP line runs at
+    lo, hi = 0.0, 8.0
+    for _ in range(14):
+        mid = 0.5 * (lo + hi)
+        model.model.centermap_parser.conf_thresh = mid
+        r = model.forward_batch(images)
+        kept = 0 if r is None else r['cam'].shape[0] / args.batch
+        if 10.0 <= kept <= 14.0:
+            break
+        lo, hi = (mid, hi) if kept > 14.0 else (lo, mid)
     n = 0
     for _ in range(args.warmup):
         r = model.forward_batch(images, pads)
@@ -301,8 +309,7 @@ def main():
     settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
     settings.conv_math, settings.backbone = args.conv_math, args.backbone
     if args.backbone == 'resnet50':
-        from oracle import resnet_oracle as RO          # seeded synthetic weights only (the generator lives with the oracle)
-        sd = RO.make_resnet_state_dict(0, center_bias=2.0)
+        sd = S.make_resnet_state_dict(0, center_bias=2.0)
         args.no_cpu_baseline = True                      # the cpu_baseline leg times the HRNet-32 oracle
     else:
         sd = S.make_romp_state_dict(0)
@@ -325,6 +332,20 @@ def main():
     images = S.make_images(B, seed=1 + rank, device=dev)
     stream = torch.cuda.Stream(dev)
     persons = 0
+    if args.backbone == 'resnet50':
+        # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
+        # ~12 persons per image, the load the HRNet-32 line runs at
+        lo, hi = -8.0, 16.0
+        with torch.cuda.stream(stream):
+            for _ in range(16):
+                mid = 0.5 * (lo + hi)
+                model.centermap_parser.conf_thresh = mid
+                out, _ = model.forward_batch(images)
+                kept = 0 if out is None else out['cam'].shape[0] / B
+                if 10.0 <= kept <= 14.0:
+                    break
+                lo, hi = (mid, hi) if kept > 14.0 else (lo, mid)
+        args.center_thresh = round(mid, 4)
 
     def step():
         nonlocal persons

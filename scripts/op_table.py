@@ -9,9 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 math = sys.argv[2] if len(sys.argv) > 2 else 'bf16x3'
 dev = torch.device('cuda:0')
 if len(sys.argv) > 3 and sys.argv[3] == 'bev':
-    from oracle import bev_oracle as BO
     from romp_amd.bev_plan import build_bev_hrnet32
-    net = RompNet(BO.make_bev_state_dict(0), dev, max_batch=B, builder=build_bev_hrnet32,
+    net = RompNet(S.make_bev_state_dict(0), dev, max_batch=B, builder=build_bev_hrnet32,
                   out_shapes=((64, 128, 128), (3, 64, 128, 128)), bf16x3=(math == 'bf16x3'))
 else:
     net = RompNet(S.make_romp_state_dict(0), dev, max_batch=B, bf16x3=(math == 'bf16x3'))
