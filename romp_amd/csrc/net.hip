@@ -159,6 +159,16 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
     }
 }
 
+// Captured graphs hold the kernel choices / stream topology of the moment they were captured.  Dropping them is rare
+// (re-tuning, option changes, cache overflow, teardown); the device is drained first so that no replay of a graph --
+// nor any of the runtime's deferred clean-up for one -- is still in flight when its executable is destroyed.
+static void drop_graphs(romp_net* n) {
+    if (n->graphs.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
+    n->graphs.clear();
+}
+
 static const std::vector<int>* tuned_for(romp_net* n, int B) {
     auto it = n->tuned.find(B);
     return it == n->tuned.end() ? nullptr : &it->second;
@@ -287,8 +297,7 @@ int romp_net_set_mode(romp_net* n, int mode) {
 int romp_net_set_streams(romp_net* n, int enable) {
     ROMP_REQUIRE(n, "romp_net_set_streams: null net");
     n->use_streams = enable ? 1 : 0;
-    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
-    n->graphs.clear();
+    drop_graphs(n);
     return ROMP_OK;
 }
 
@@ -298,8 +307,7 @@ int romp_net_set_split(romp_net* n, int lanes, int wg_cap, int64_t image_floats,
     n->split = lanes;
     n->wg_cap = wg_cap;
     n->image_floats = image_floats; n->center_floats = center_floats; n->params_floats = params_floats;
-    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
-    n->graphs.clear();
+    drop_graphs(n);
     return ROMP_OK;
 }
 
@@ -319,8 +327,7 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
         // a caller that hands over new tensors every call must not grow the cache for ever
         ROMP_HIP_CHECK(hipStreamSynchronize(st));
         ROMP_HIP_CHECK(hipStreamSynchronize(n->lane_main));
-        for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
-        n->graphs.clear();
+        drop_graphs(n);
     }
     auto capture = [&](hipStream_t origin, const GraphKey& key, auto&& body) -> int {
         if (n->graphs.count(key)) return ROMP_OK;
@@ -405,8 +412,7 @@ int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
     hipEventDestroy(e1);
     if (rc == ROMP_OK) {
         n->tuned[B] = best;
-        for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);     // captured with the old choices
-        n->graphs.clear();
+        drop_graphs(n);
     }
     return rc;
 }
@@ -461,7 +467,7 @@ int romp_net_write_buffer(romp_net* n, int buf, const float* src, int64_t n_floa
 
 void romp_net_destroy(romp_net* n) {
     if (!n) return;
-    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
+    drop_graphs(n);
     for (float* p : n->bufs)
         if (p) hipFree(p);
     if (n->queues) hipFree(n->queues);
@@ -525,8 +531,7 @@ int romp_net_set_tuned(romp_net* n, int B, const int32_t* variants, int n_ops) {
         tv[i] = variants[i];
     }
     n->tuned[B] = tv;
-    for (auto& kv : n->graphs) hipGraphExecDestroy(kv.second);
-    n->graphs.clear();
+    drop_graphs(n);
     return ROMP_OK;
 }
 
