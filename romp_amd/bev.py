@@ -15,7 +15,6 @@ import ctypes as C
 import os.path as osp
 import sys
 
-import numpy as np
 import torch
 from torch import nn
 

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_BEV_MAPS, OP_BEV_PACK, OP_CONV, OP_CONV3D, OP_FORK,
+from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_STEM, RompOp)
 
 BN_EPS = 1e-5

@@ -1,6 +1,5 @@
 """BEV post-processing (projection, duplicate suppression, outlier removal) and device pre-processing.
 CPU: oracle vs the reference-generated fixture bev_post.npz.  GPU: HIP kernels (csrc/post.hip) vs both."""
-import ctypes as C
 import os
 
 import numpy as np

@@ -5,7 +5,6 @@ import ctypes as C
 import os
 import re
 import subprocess
-import sys
 import tempfile
 
 import numpy as np

@@ -5,7 +5,6 @@ CPU with gloo in test_distributed_gloo.py; the 8-GPU run is the driver's.)"""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
