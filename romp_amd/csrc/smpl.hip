@@ -227,26 +227,28 @@ __global__ __launch_bounds__(256) void smpl_skin_kernel(const float* __restrict_
 }
 
 // ---- kernel C: joint regression ---------------------------------------------------------------
-__global__ __launch_bounds__(1024) void smpl_joints_kernel(const float* __restrict__ verts, const float* __restrict__ reg,
-                                                           const int* __restrict__ pick, int root_align,
-                                                           float* __restrict__ joints, float* __restrict__ root) {
-    __shared__ float s_part[16][NREG * 3];
-    __shared__ float s_root[3];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One workgroup per (person, quarter of the 26 regressed joints): at N = 64 a workgroup per person left three quarters
+// of the CUs idle and made this the longest SMPL kernel.
+constexpr int JSPLIT = 4, RPS = (NREG + JSPLIT - 1) / JSPLIT;          // 7 regressors per workgroup
+__global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restrict__ verts, const float* __restrict__ reg,
+                                                           const int* __restrict__ pick, float* __restrict__ joints) {
+    __shared__ float s_part[4][RPS * 3];
+    const int n = blockIdx.x, r0 = blockIdx.y * RPS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nr = min(RPS, NREG - r0);
     const float* vn = verts + (size_t)n * NV * 3;
-    float acc[NREG][3];
+    float acc[RPS][3];
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
-    for (int v = tid; v < NV; v += 1024) {
+    for (int r = 0; r < RPS; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
+    for (int v = tid; v < NV; v += 256) {
         const float x = vn[v * 3], y = vn[v * 3 + 1], z = vn[v * 3 + 2];
 #pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-            const float w = reg[(size_t)r * NV + v];
+        for (int r = 0; r < RPS; ++r) {
+            const float w = reg[(size_t)min(r0 + r, NREG - 1) * NV + v];
             acc[r][0] = fmaf(w, x, acc[r][0]); acc[r][1] = fmaf(w, y, acc[r][1]); acc[r][2] = fmaf(w, z, acc[r][2]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < NREG; ++r)
+    for (int r = 0; r < RPS; ++r)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float a = acc[r][k];
@@ -255,17 +257,18 @@ __global__ __launch_bounds__(1024) void smpl_joints_kernel(const float* __restri
         }
     __syncthreads();
     float* jn = joints + (size_t)n * NJOUT * 3;
-    if (tid < NREG * 3) {                                    // joints 45..70: extra9 then h36m17 (smpl.py:26-29)
-        float a = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 16; ++wv) a += s_part[wv][tid];
-        jn[(NJ + NPICK) * 3 + tid] = a;
-    }
-    if (tid < NPICK * 3)                                     // joints 24..44: vertex picks (smpl.py:25)
+    if (tid < nr * 3)                                        // joints 45..70: extra9 then h36m17 (smpl.py:26-29)
+        jn[(NJ + NPICK + r0) * 3 + tid] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+    if (blockIdx.y == 0 && tid < NPICK * 3)                  // joints 24..44: vertex picks (smpl.py:25)
         jn[NJ * 3 + tid] = vn[pick[tid / 3] * 3 + tid % 3];
-    if (!root_align) return;
-    __syncthreads();
-    if (tid < 3) {                                           // joints54[:,[45,46]].mean(1)  (smpl.py:104)
+}
+
+// root alignment (smpl.py:102-106): root = joints[45:47].mean(0); joints -= root (vertices: smpl_root_sub_kernel)
+__global__ __launch_bounds__(256) void smpl_root_joints_kernel(float* __restrict__ joints, float* __restrict__ root) {
+    __shared__ float s_root[3];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float* jn = joints + (size_t)n * NJOUT * 3;
+    if (tid < 3) {
         const float r0 = (jn[45 * 3 + tid] + jn[46 * 3 + tid]) / 2.f;
         s_root[tid] = r0;
         root[n * 3 + tid] = r0;
@@ -388,9 +391,10 @@ int smpl_forward(smpl_ctx* c, const float* betas, int n_betas, const float* thet
         hipLaunchKernelGGL(smpl_skin_kernel<11>, grid, dim3(256), 0, st, betas, c->pose_feat, c->Amat, c->vt, c->sd, c->pd,
                            c->lbsw, N, verts);
     ROMP_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(smpl_joints_kernel, dim3(N), dim3(1024), 0, st, verts, c->reg, c->pick, root_align, joints, c->root);
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(N, JSPLIT), dim3(256), 0, st, verts, c->reg, c->pick, joints);
     ROMP_HIP_CHECK(hipGetLastError());
     if (root_align) {
+        hipLaunchKernelGGL(smpl_root_joints_kernel, dim3(N), dim3(256), 0, st, joints, c->root);
         const size_t total = (size_t)N * NV * 3;
         size_t blocks = (total + 255) / 256;
         if (blocks > 4096) blocks = 4096;
