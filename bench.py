@@ -32,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 BX3_PRODUCTS = 6                  # bf16 piece products issued per f32 product by the bf16x3 kernels
+H2_PRODUCTS = 3                   # fp16 piece products issued per f32 product by the f16x2 kernels
 PEAK_HBM_GBS = 8000.0
 
 
@@ -45,8 +46,9 @@ def parse_args():
     ap.add_argument('--workload', type=str, default='romp', choices=['romp', 'bev', 'smpl'],
                     help="romp = BASELINE configs[1] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A); smpl = configs[4] (SMPL-only, 64 persons)")
     ap.add_argument('--graph', type=int, default=1, help='replay the network from a hipGraph')
-    ap.add_argument('--conv-math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
-                    help='f32: exact f32 MFMA kernels only; bf16x3: also offer the f32-accurate bf16x3-split kernels to the autotuner')
+    ap.add_argument('--conv-math', type=str, default='f16x2', choices=['f32', 'bf16x3', 'f16x2', 'all'],
+                    help='f32: exact f32 MFMA kernels only; f16x2 / bf16x3 / all: also offer the f32-accurate split-precision kernels '
+                         '(2 fp16 pieces x 3 products / 3 bf16 pieces x 6 products) to the autotuner')
     ap.add_argument('--streams', type=int, default=1, help='run independent HRNet branches on side HIP streams')
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
     ap.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
@@ -89,11 +91,13 @@ def roofline_report(model, images, lib, L):
     # bf16 MFMA products per algorithmic product, so its roof is the bf16 dense peak / 6; the f32 kernels
     # are priced against the f32 MFMA peak.
     bx3 = 'conv_bx' in name                  # conv_bx3_* and conv_bxd_*: the bf16x3-split kernels
-    peak = PEAK_BF16_MFMA_TFLOPS / BX3_PRODUCTS if bx3 else PEAK_F32_MFMA_TFLOPS
+    h2 = 'conv_h2' in name                   # conv_h2_* and conv_h2d_*: the f16x2-split kernels
+    products = BX3_PRODUCTS if bx3 else H2_PRODUCTS if h2 else 1
+    peak = PEAK_BF16_MFMA_TFLOPS / products if (bx3 or h2) else PEAK_F32_MFMA_TFLOPS
     roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
                 frac=round(achieved / peak, 4), traffic=None,
-                pipe='bf16 MFMA 32x32x16, %d piece products per f32 product' % BX3_PRODUCTS if bx3 else 'f32 MFMA 32x32x2',
-                issued_tflops=round(achieved * (BX3_PRODUCTS if bx3 else 1), 1),
+                pipe=('%s MFMA 32x32x16, %d piece products per f32 product' % ('bf16' if bx3 else 'f16', products)) if (bx3 or h2) else 'f32 MFMA 32x32x2',
+                issued_tflops=round(achieved * products, 1),
                 frac_of_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 launches=a['launches'], avg_launch_ms=round(a['ms'] / a['launches'], 5),
                 flops_per_launch=a['flops'] / a['launches'], alg_bytes_per_launch=a['bytes'] / a['launches'],
@@ -114,7 +118,7 @@ def pmc_traffic(variant_name, pmc_dir):
     None if the files or the kernel are missing -- PMC counters cannot be read from inside this process."""
     import csv
     import re
-    m = re.match(r'conv_(mfma|pp|bx3|bxd)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2|h2d)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
     kern = 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % m.groups()
@@ -278,7 +282,7 @@ def bench_bev(args, dev):
     print(json.dumps({'metric': 'images/sec (512x512, BEV HRNet-32)', 'value': round(args.batch * args.steps / dt, 2),
                       'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
                       'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-                      'vs_baseline': None, 'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (bf16x3-split conv products)', 'data': 'synthetic',
+                      'vs_baseline': None, 'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (%s-split conv products)' % args.conv_math, 'data': 'synthetic',
                       'config': {'workload': 'BEV HRNet-32 + BEV head 512x512 batch=%d (BASELINE configs[3]); net+3D parse+'
                                              'regression+SMPL-A+post-processing' % args.batch,
                                  'persons_kept_per_image': round(n / args.batch, 2), 'net_ms_per_batch': round(sum(ms), 3),
@@ -381,7 +385,7 @@ def main():
         'metric': 'images/sec (512x512, %s)' % ('HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'), 'value': round(total_images / dt, 2), 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as bf16x3-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)',
+        'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as %s-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)' % args.conv_math,
         'data': 'synthetic',
         'config': {'workload': (('ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); ' if args.backbone == 'hrnet32'
                                  else 'ROMP ResNet-50 512x512 (BASELINE configs[0] model), batch=%d synthetic images per GPU; ') +
@@ -395,7 +399,7 @@ def main():
                 roof, classes = roofline_report(model, images, lib, L)
             result['roofline'] = roof
             result['kernel_classes'] = classes
-        if world == 1 and args.conv_math == 'bf16x3' and args.backbone == 'hrnet32' and not args.no_f32_companion:
+        if world == 1 and args.conv_math != 'f32' and args.backbone == 'hrnet32' and not args.no_f32_companion:
             # the same workload with every conv on the exact-f32 MFMA kernels only, for readers who do not accept the
             # bf16x3 split as float32 arithmetic (it passes the same 1e-4 gate): same steps, same timing discipline
             del model

@@ -37,7 +37,7 @@ extern "C" {
 #define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
 #define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
 
-#define ROMP_ABI_VERSION 2
+#define ROMP_ABI_VERSION 3
 
 int         romp_abi_version(void);
 const char* romp_last_error(void);
@@ -89,12 +89,17 @@ typedef struct romp_op {
                                      ksize 2 (one output parity of ConvTranspose2d k4 s2 p1): 1 or 0               */
     int32_t out_rstride, out_bstride;  /* CONV: output row / image stride in floats; 0 = dense (Wo*out_cstride,
                                      Ho*Wo*out_cstride).  Sparse strides interleave the parity outputs of a transposed conv */
-    int32_t reserved;
+    int32_t act_shift;            /* CONV, f16x2 kernels: activations are multiplied by 2^act_shift before they are split
+                                     into fp16 pieces (keeps the low piece out of the fp16 subnormal range; |x| must stay
+                                     below 65504 / 2^act_shift).  scale_h2 carries the inverse.                       */
     const float* weight;          /* packed [group][chunk][tap][cin/4][cout_pad][4]       */
     const float* scale;           /* [group][cout_pad]  gamma/sqrt(var+eps)  (or 1)       */
     const float* shift;           /* [group][cout_pad]  beta-mean*scale (+scale*bias)     */
     const void*  weight_aux;      /* optional: the same weights split into 3 bf16 pieces,
                                      [group][tap][cin_pad/16][piece 3][kg 2][cout_pad][8] (bf16x3 kernels) */
+    const void*  weight_h2;       /* optional: the weights, multiplied by a per-group power of two 2^ws, split into
+                                     2 fp16 pieces, [group][tap][cin_pad/16][piece 2][kg 2][cout_pad][8] (f16x2 kernels) */
+    const float* scale_h2;        /* [group][cout_pad]  scale * 2^-(ws + act_shift): the f16x2 kernels' epilogue scale */
 } romp_op;
 
 typedef struct romp_net romp_net;

@@ -48,8 +48,8 @@ def bev_settings(input_args=sys.argv[1:]):
     p.add_argument('--model_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'BEV.pth'))
     p.add_argument('-t', '--temporal_optimize', action='store_true')
     p.add_argument('--max_batch', type=int, default=32)
-    p.add_argument('--conv_math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
-                   help='[romp_amd] f32 MFMA only, or also the f32-accurate bf16x3-split kernels (chosen by autotune)')
+    p.add_argument('--conv_math', type=str, default='f16x2', choices=['f32', 'bf16x3', 'f16x2', 'all'],
+                   help='[romp_amd] f32 MFMA only, or also the f32-accurate split-precision kernels (f16x2: 2 fp16 pieces; bf16x3; chosen by autotune)')
     args = p.parse_args(input_args)
     if not torch.cuda.is_available():
         args.GPU = -1
@@ -174,7 +174,7 @@ class BEV(nn.Module):
             state_dict = torch.load(settings.model_path, map_location='cpu')
         self.model = BEVv1(state_dict, self.tdevice, center_thresh=settings.center_thresh,
                            max_batch=getattr(settings, 'max_batch', 32),
-                           bf16x3=getattr(settings, 'conv_math', 'bf16x3') == 'bf16x3')
+                           bf16x3=getattr(settings, 'conv_math', 'f16x2'))
         if settings.calc_smpl:
             self.smpl_parser = SMPLA_parser(smpla_model if smpla_model is not None else settings.smpl_path,
                                             smil_model if smil_model is not None else settings.smil_path).to(self.tdevice)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .lib import BUF_CENTER, BUF_NONE, BUF_PARAMS, OP_BEV_MAPS, OP_BEV_PACK, OP_CONV3D, RompOp
-from .plan import Act, Program, _clean, build_hrnet32_backbone, fold_bn
+from .plan import Act, Program, _clean, build_hrnet32_backbone, fold_bn, set_conv_math
 
 MAP, DEPTH, VOX = 128, 64, 64 * 128 * 128
 
@@ -43,7 +43,7 @@ def build_bev_hrnet32(sd, device, input_size=512, bf16x3=False) -> Program:
     assert input_size == 512, 'the BEV head is defined on a 128x128 map (bev/model.py:117)'
     sd = _clean(sd)
     P = Program(device)
-    P.bf16x3 = bool(bf16x3)
+    set_conv_math(P, bf16x3)
     x = build_hrnet32_backbone(P, sd, input_size, out_cstride=32)          # (B,128,128,32)
 
     def bn(name, c, bias=None):

@@ -1,0 +1,166 @@
+// conv_common.h -- shared pieces of the conv kernel translation units (gfx950 only): launch parameters,
+// tile configuration, work-item decoding, the fused epilogue and the variant table entry.
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+
+namespace romp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* in; const float* w; const float* scale; const float* shift; const float* res;
+    float* out;
+    const uint4* w3;          // bf16x3-split weights (conv_bx3 / conv_bxd kernels), or nullptr
+    const uint4* wh;          // f16x2-split weights (conv_h2 / conv_h2d kernels), or nullptr
+    const float* scale_h;     // their epilogue scale (scale / (weight scale * act_scale))
+    float act_scale;          // 2^act_shift, applied to the activations before the fp16 split
+    int* queue;               // 8 per-XCD work counters, QUEUE_STRIDE ints apart, zeroed before the launch
+    int H, W, Ho, Wo;
+    int Cout;                 // valid output channels per group (store mask)
+    int cin_valid;            // channels physically present in the input (loader mask)
+    int cin_pad, cout_pad;    // packed weight dims
+    int in_cs, in_co, in_gs;
+    int out_cs, out_co, out_gs;
+    int res_cs, res_co, res_gs;
+    int relu;
+    int tiles_x, tiles_y, tiles_total;
+    int nslices, ns_total;    // channel slices per group; slices*groups
+    int n_queues, per_queue;  // 8 (XCD-aware) or 1
+    int vec_io;               // epilogue may use float4 loads/stores
+    int w_gs;                 // floats per group in the packed weight
+    int pad_h, pad_w;         // rows / columns of zero padding before the first tap
+    int out_rs, out_bs;       // output row stride / image stride in floats (dense: Wo*out_cs, Ho*Wo*out_cs)
+    int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
+                              // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
+                              // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
+                              // only the pixel loads / only the weight DMA.  scripts/conv_ablate.py and DESIGN.md §4 use them.
+};
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int KS, int S, int MT, int NT, int TW, int CK>
+struct ConvCfg {
+    // KS = 1: 1x1, 2: 2x2 (one output parity of a ConvTranspose2d k4 s2), 3: 3x3, 13: 1x3 (Conv1d k=3 along W; rows of
+    // the "image" are independent sequences).  The zero padding before the first tap is a run-time parameter.
+    static constexpr int KH = (KS == 13) ? 1 : KS;
+    static constexpr int KW = (KS == 13) ? 3 : KS;
+    static constexpr int TAPS = KH * KW;
+    static constexpr int RPB = 32 / TW;              // tile rows per 32-pixel block
+    static constexpr int TH = 4 * MT * RPB;          // output tile rows
+    static constexpr int HR = (TH - 1) * S + KH;     // haloed input rows
+    static constexpr int HC = (TW - 1) * S + KW;
+    static constexpr int PS = CK + 4;                // LDS floats per pixel (padded)
+    static constexpr int NW = NT * 32;               // output channels per work item
+    static constexpr int QC = CK / 4;                // float4 per pixel per chunk
+    static constexpr int A_VEC = HR * HC * QC;
+    static constexpr int B_VEC = TAPS * QC * NW;
+    static constexpr int NA = (A_VEC + 255) / 256;
+    static constexpr int NB = (B_VEC + 255) / 256;
+    static constexpr int LDS_BYTES = (HR * HC * PS + TAPS * CK * NW + 4 * NW) * 4 + 16;
+};
+
+struct Item { int b, ty, tx, n0, g; };
+
+__device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, int NW) {
+    const int s = j % p.ns_total, tl = j / p.ns_total;
+    int t = tl * p.n_queues + q;
+    Item it;
+    it.g = s / p.nslices;
+    it.n0 = (s % p.nslices) * NW;
+    it.tx = t % p.tiles_x; t /= p.tiles_x;
+    it.ty = t % p.tiles_y;
+    it.b = t / p.tiles_y;
+    return it;
+}
+
+// Epilogue of one work item: y = acc*scale + shift (+ residual) (ReLU), NHWC float4 stores.
+// Lane owns pixel li of pixel-block m and channels n0 + n*32 + 8*g4 + 4*lh + {0..3}.
+// All residual loads of the item are issued up front in ONE batch under ONE uniform branch (a
+// branch per float4 serialises MT*NT*4 dependent global round trips -- that alone held the
+// 3x3 kernels at ~100 TFLOP/s), ReLU is branch-free (max with 0 or -inf).
+template <int KS, int S, int MT, int NT, int TW, int CK>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][NT],
+                                              const float* sSc, int wave, int li, int lh) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+    float* out = p.out + (size_t)cur.b * p.out_bs + p.out_co + cur.g * p.out_gs;
+    const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
+    const float floor_v = p.relu ? 0.f : -__builtin_inff();
+    unsigned pixo[MT], outo[MT];                     // residual pixel index; output offset (row / pixel strides may be sparse)
+    bool rowok[MT];                                  // partial tiles along H (e.g. Conv1d over B < TH sequences)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mb = wave * MT + m;
+        const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
+        rowok[m] = oy < p.Ho;
+        pixo[m] = rowok[m] ? (unsigned)(oy * p.Wo + ox) : 0u;
+        outo[m] = rowok[m] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
+    }
+    if (p.vec_io) {
+        float4 r[MT][NT][4];
+        if (res) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        r[m][n][g4] = ldg4(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8 + lh * 4)));   // masked rows read pixel 0 (valid memory)
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) r[m][n][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cl = n * 32 + g4 * 8 + lh * 4;
+                const float4 sc = *reinterpret_cast<const float4*>(sSc + cl);
+                const float4 sh = *reinterpret_cast<const float4*>(sSc + C::NW + cl);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float4 v;
+                    v.x = fmaxf(fmaf(acc[m][n][g4 * 4 + 0], sc.x, sh.x) + r[m][n][g4].x, floor_v);
+                    v.y = fmaxf(fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y) + r[m][n][g4].y, floor_v);
+                    v.z = fmaxf(fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z) + r[m][n][g4].z, floor_v);
+                    v.w = fmaxf(fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w) + r[m][n][g4].w, floor_v);
+                    if (rowok[m]) *reinterpret_cast<float4*>(out + (outo[m] + (unsigned)(cur.n0 + cl))) = v;
+                }
+            }
+    } else {
+        // scalar path: output convs of the head (Cout = 142 / 1 / 3 into unaligned NHWC slots)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cl = n * 32 + g4 * 8 + lh * 4;
+                    const int co = cur.n0 + cl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.Cout && rowok[m]) {
+                            float t = fmaf(acc[m][n][g4 * 4 + e], sSc[cl + e], sSc[C::NW + cl + e]);
+                            if (res) t += res[pixo[m] * (unsigned)p.res_cs + (unsigned)(co + e)];
+                            out[outo[m] + (unsigned)(co + e)] = fmaxf(t, floor_v);
+                        }
+                    }
+                }
+    }
+}
+
+typedef void (*conv_fn)(ConvParams);
+// math: 0 f32 MFMA, 1 bf16x3 (register-staged weights), 2 bf16x3 (LDS-DMA weight rows), 3 / 4 the same two for f16x2
+struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; };
+
+// per translation unit: its table of instantiated kernels
+ConvVariant* conv_variants_f32(int* n);
+ConvVariant* conv_variants_bx3(int* n);
+ConvVariant* conv_variants_h2(int* n);
+ConvVariant* conv_variants_h2d(int* n);
+
+}  // namespace romp

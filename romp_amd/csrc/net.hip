@@ -7,6 +7,7 @@
 // caller's stream -- eagerly, or from a hipGraph captured per (batch, I/O pointers) so that the
 // ~330 dependent launches of one forward cost one graph launch on the host.
 #include "common.h"
+#include <algorithm>
 #include <vector>
 #include <map>
 #include <tuple>
@@ -379,12 +380,32 @@ int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
     std::vector<int> best(n->ops.size(), -1);
-    hipEvent_t e0, e1;
-    ROMP_HIP_CHECK(hipEventCreate(&e0));
-    ROMP_HIP_CHECK(hipEventCreate(&e1));
-    // scratch targets for ops that read the caller's image / write the caller's output tensors
+    // Scratch target for ops that read the caller's image or write the caller's output tensors: sized from the program
+    // (largest per-image extent any conv touches through a pseudo buffer), not from one model's head.
+    size_t scratch_floats = 16;
+    for (const romp_op& op : n->ops) {
+        if (op.kind != ROMP_OP_CONV) continue;
+        const int kh = op.ksize == 13 ? 1 : op.ksize, kw = op.ksize == 13 ? 3 : op.ksize;
+        const int Ho = op.ksize == 2 ? op.H / op.stride : (op.H + 2 * (kh / 2) - kh) / op.stride + 1;
+        const int Wo = op.ksize == 2 ? op.W / op.stride : (op.W + 2 * (kw / 2) - kw) / op.stride + 1;
+        if (op.in_buf == ROMP_BUF_IMAGE) scratch_floats = std::max(scratch_floats, (size_t)op.H * op.W * op.in_cstride);
+        if (op.res_buf == ROMP_BUF_IMAGE) scratch_floats = std::max(scratch_floats, (size_t)Ho * Wo * op.res_cstride);
+        if (op.out_buf == ROMP_BUF_CENTER || op.out_buf == ROMP_BUF_PARAMS)
+            scratch_floats = std::max(scratch_floats, op.out_bstride > 0 ? (size_t)op.out_bstride : (size_t)Ho * Wo * op.out_cstride);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float* scratch = nullptr;
-    ROMP_HIP_CHECK(hipMalloc((void**)&scratch, (size_t)B * 64 * 64 * 145 * sizeof(float)));
+    auto cleanup = [&]() {
+        if (scratch) hipFree(scratch);
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+    };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess ||
+        hipMalloc((void**)&scratch, scratch_floats * (size_t)B * sizeof(float)) != hipSuccess) {
+        cleanup();
+        set_error("autotune: event / scratch allocation failed (%zu floats x %d)", scratch_floats, B);
+        return ROMP_ENOMEM;
+    }
     int rc = ROMP_OK;
     for (size_t i = 0; i < n->ops.size() && rc == ROMP_OK; ++i) {
         const romp_op& op = n->ops[i];
@@ -407,9 +428,7 @@ int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
             if (ms_min < best_ms) { best_ms = ms_min; best[i] = v; }
         }
     }
-    hipFree(scratch);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    cleanup();
     if (rc == ROMP_OK) {
         n->tuned[B] = best;
         drop_graphs(n);

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libromp_hip.so')
 
-ABI_VERSION = 2          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
+ABI_VERSION = 3          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
 OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN, OP_BEV_PACK, OP_BEV_MAPS, OP_CONV3D = 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -31,8 +31,9 @@ class RompOp(C.Structure):
         ('n_terms', C.c_int32),
         ('term_buf', C.c_int32 * 4), ('term_shift', C.c_int32 * 4), ('term_cstride', C.c_int32 * 4),
         ('stream', C.c_int32), ('pad_h', C.c_int32), ('pad_w', C.c_int32), ('out_rstride', C.c_int32), ('out_bstride', C.c_int32),
-        ('reserved', C.c_int32),
+        ('act_shift', C.c_int32),
         ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('weight_aux', C.c_void_p),
+        ('weight_h2', C.c_void_p), ('scale_h2', C.c_void_p),
     ]
 
 

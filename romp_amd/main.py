@@ -51,9 +51,10 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--root_align', type=bool, default=False, help='Please set this config as True to use the ROMP checkpoints trained by yourself.')
     parser.add_argument('--webcam_id', type=int, default=0, help='The Webcam ID.')
     parser.add_argument('--max_batch', type=int, default=32, help='[romp_amd] largest batch forward_batch will be called with')
-    parser.add_argument('--conv_math', type=str, default='bf16x3', choices=['f32', 'bf16x3'],
-                        help='[romp_amd] f32: f32 MFMA kernels only; bf16x3 (default): also the f32-accurate 3-way bf16 split kernels on the '
-                             'bf16 matrix pipe, chosen per layer by measurement the first time a batch size is seen')
+    parser.add_argument('--conv_math', type=str, default='f16x2', choices=['f32', 'bf16x3', 'f16x2', 'all'],
+                        help='[romp_amd] f32: exact-f32 MFMA kernels only; f16x2 (default) / bf16x3: also offer the f32-accurate split-precision kernels '
+                             '(2 fp16 pieces, 3 products / 3 bf16 pieces, 6 products) on the 16-bit matrix pipe, chosen per layer by measurement the first '
+                             'time a batch size is seen; all: both families')
     parser.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
                         help='[romp_amd] hrnet32: the simple_romp model (ROMP.pkl); resnet50: the training tree\'s ResNet-50 variant '
                              '(romp/lib/models/resnet_50.py + romp_model.py state_dict)')
@@ -97,7 +98,7 @@ class ROMP(nn.Module):
         if getattr(self.settings, 'backbone', 'hrnet32') == 'resnet50':
             from .resnet_plan import build_romp_resnet50 as builder
         self.model = RompNet(state_dict, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32), builder=builder,
-                             bf16x3=getattr(self.settings, 'conv_math', 'bf16x3') == 'bf16x3')
+                             bf16x3=getattr(self.settings, 'conv_math', 'f16x2'))
 
     def _initilization_(self, smpl_model=None):
         self.centermap_parser = CenterMap(conf_thresh=self.settings.center_thresh)

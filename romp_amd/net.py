@@ -17,13 +17,14 @@ class RompNet:
     def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
                  out_shapes=None, bf16x3=False):
         """`builder(state_dict, device, input_size, bf16x3=) -> Program` (default: ROMP HRNet-32 + head);
-        `out_shapes`: per-image shapes of the two output tensors of the program."""
+        `out_shapes`: per-image shapes of the two output tensors of the program.  `bf16x3` is the conv_math
+        setting: False / 'f32', True / 'bf16x3', 'f16x2' or 'all' (plan.set_conv_math)."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
         self.lib = L.load()
         self.max_batch = int(max_batch)
-        self.bf16x3 = bool(bf16x3)
+        self.bf16x3 = bf16x3 not in (False, None, 'f32')      # split-precision kernels on offer: pick by measurement
         self._tuned = set()
         self.split = 1
         self.input_size = input_size
@@ -75,6 +76,10 @@ class RompNet:
         assert image.dtype == torch.float32 and image.is_cuda and image.dim() == 4 and image.shape[-1] == 3
         image = image.contiguous()
         B = image.shape[0]
+        if tuple(image.shape[1:3]) != (self.input_size, self.input_size):
+            raise L.RompHipError('RompNet was lowered for %dx%d inputs, got %dx%d' % (self.input_size, self.input_size, image.shape[1], image.shape[2]))
+        if B > self.max_batch:
+            raise L.RompHipError('batch %d > max_batch %d' % (B, self.max_batch))
         Bt = B // 2 if (self.split == 2 and B >= 2 and B % 2 == 0) else B     # batch the kernels really see
         if self.bf16x3 and Bt not in self._tuned:     # the bf16x3 kernels are only ever picked by measurement
             self.autotune(Bt)

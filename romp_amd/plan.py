@@ -13,6 +13,7 @@ What is NOT here: any arithmetic of the hot path.  The program is executed by
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -94,6 +95,42 @@ def pack_conv_weight_bx3(w, cin_pad, cout_pad):
     return t.permute(1, 2, 0, 3, 5, 4).contiguous().view(torch.int16)
 
 
+def pack_conv_weight_h2(w, cin_pad, cout_pad):
+    """Weights for the f16x2 conv kernels: multiplied by a power of two 2^ws that puts max|w| in (128, 256] (exact; keeps
+    the low piece of every weight that matters out of the fp16 subnormal range), then split into two fp16 pieces
+    (w*2^ws = h1 + h2 up to 2^-22 relative, round-to-nearest-even like the device-side activation split).
+    -> (int16 tensor [tap][cin_pad/16][piece 2][kg 2][cout_pad][8], ws)."""
+    if w.dim() == 3:
+        w = w.unsqueeze(2)
+    cout, cin, kh, kw = w.shape
+    full = torch.zeros(kh * kw, cin_pad, cout_pad, dtype=torch.float32)
+    full[:, :cin, :cout] = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    m = float(full.abs().max())
+    ws = 0 if m == 0.0 or not math.isfinite(m) else int(math.floor(math.log2(256.0 / m)))
+    ws = max(-24, min(24, ws))
+    full = full * (2.0 ** ws)
+    p1 = full.half()
+    p2 = (full - p1.float()).half()
+    t = torch.stack([p1, p2]).reshape(2, kh * kw, cin_pad // 16, 2, 8, cout_pad)
+    return t.permute(1, 2, 0, 3, 5, 4).contiguous().view(torch.int16), ws
+
+
+ACT_SHIFT = 4            # f16x2 kernels: activations are split as fp16 pieces of 16*x (|x| < 4094)
+
+
+def set_conv_math(P, conv_math):
+    """Which split-precision weight packs a Program carries (the kernels are then offered to the autotuner):
+    False / 'f32': none; True / 'bf16x3': 3 bf16 pieces; 'f16x2': 2 fp16 pieces; 'all': both."""
+    if conv_math is True:
+        conv_math = 'bf16x3'
+    if conv_math in (False, None):
+        conv_math = 'f32'
+    assert conv_math in ('f32', 'bf16x3', 'f16x2', 'all'), conv_math
+    P.conv_math = conv_math
+    P.bf16x3 = conv_math in ('bf16x3', 'all')
+    P.f16x2 = conv_math in ('f16x2', 'all')
+
+
 class Program:
     """The lowered network: ops (ctypes), packed constants (kept alive here), buffer sizes."""
 
@@ -110,7 +147,9 @@ class Program:
         self.cur_stream = 0
         self.in_parallel = False
         self.parallel = True                                   # emit FORK/JOIN (False: one stream)
-        self.bf16x3 = False                                    # also pack bf16x3-split weights (conv_bx3 kernels)
+        self.bf16x3 = False                                    # also pack bf16x3-split weights (conv_bx3 / conv_bxd kernels)
+        self.f16x2 = False                                     # also pack f16x2-split weights (conv_h2 / conv_h2d kernels)
+        self.conv_math = 'f32'
         self.persistent = set()
         self.head_in_buf: Optional[int] = None
         self.head_in_ch, self.coord_off = HEAD_IN_CH, None     # coord_off: first of the two constant CoordConv channels
@@ -221,6 +260,14 @@ class Program:
         op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
         if paux is not None:
             op.weight_aux = paux.data_ptr()
+        if self.f16x2 and cin_pad % 16 == 0:
+            packs = [pack_conv_weight_h2(wi, cin_pad, cout_pad) for wi in w]
+            ph = self._dev(torch.stack([pk for pk, _ in packs]))
+            psh = torch.zeros(groups, cout_pad, dtype=torch.float64)
+            for g in range(groups):
+                psh[g, :cout] = scale[g].double() * (2.0 ** -(packs[g][1] + ACT_SHIFT))      # exact
+            psh = self._dev(psh.float())
+            op.weight_h2, op.scale_h2, op.act_shift = ph.data_ptr(), psh.data_ptr(), ACT_SHIFT
         op.stream = self.cur_stream
         self.ops.append(op)
         self.names.append(name)
@@ -386,10 +433,10 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
 
 
 def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512, bf16x3=False) -> Program:
-    """state_dict of ROMPv1 (model.py:420-481) -> Program."""
+    """state_dict of ROMPv1 (model.py:420-481) -> Program.  `bf16x3`: the conv_math setting (see set_conv_math)."""
     sd = _clean(sd)
     P = Program(device)
-    P.bf16x3 = bool(bf16x3)
+    set_conv_math(P, bf16x3)
     # backbone output lands in 32 of the 40 channels of the head input buffer; channels 32,33 hold the
     # constant CoordConv maps (model.py:473), 34..39 are zero padding.
     build_hrnet32_backbone(P, sd, input_size, out_cstride=HEAD_IN_CH)

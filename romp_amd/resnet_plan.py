@@ -14,7 +14,7 @@ romp/lib/models/basic_modules.py Bottleneck :90-128, romp/lib/models/romp_model.
 import torch
 
 from .lib import RompOp
-from .plan import Act, Program, build_romp_head, fold_bn, _clean, BUF_IMAGE, BUF_NONE
+from .plan import Act, Program, build_romp_head, fold_bn, _clean, set_conv_math, BUF_IMAGE, BUF_NONE
 
 OP_STEM7, OP_MAXPOOL = 9, 10
 LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
@@ -51,7 +51,7 @@ def _maxpool(P: Program, name, x: Act):
 def build_romp_resnet50(sd, device, input_size=512, bf16x3=False) -> Program:
     sd = _clean(sd)
     P = Program(device)
-    P.bf16x3 = bool(bf16x3)
+    set_conv_math(P, bf16x3)
     bb = 'backbone.'
 
     def cbr(name, x, conv, bn, k, stride, relu, res=None):

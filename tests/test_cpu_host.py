@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), 'libromp_hip.so does not export %s' % n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert h.romp_abi_version() == L.ABI_VERSION == 2
+    assert h.romp_abi_version() == L.ABI_VERSION == 3
 
 
 def test_romp_op_struct_layout_matches_header():
@@ -38,8 +38,9 @@ def test_romp_op_struct_layout_matches_header():
     #include <stdio.h>
     #include <stddef.h>
     #include "romp_hip.h"
-    int main(void) { printf("%zu %zu %zu %zu %zu\n", sizeof(romp_op), offsetof(romp_op, groups),
-        offsetof(romp_op, term_buf), offsetof(romp_op, weight), offsetof(romp_op, shift)); return 0; }
+    int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(romp_op), offsetof(romp_op, groups),
+        offsetof(romp_op, term_buf), offsetof(romp_op, weight), offsetof(romp_op, shift), offsetof(romp_op, act_shift),
+        offsetof(romp_op, scale_h2)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, 't.c')
@@ -48,7 +49,7 @@ def test_romp_op_struct_layout_matches_header():
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
         vals = [int(v) for v in subprocess.check_output([exe]).split()]
     assert vals == [C.sizeof(RompOp), RompOp.groups.offset, RompOp.term_buf.offset, RompOp.weight.offset,
-                    RompOp.shift.offset]
+                    RompOp.shift.offset, RompOp.act_shift.offset, RompOp.scale_h2.offset]
 
 
 def test_no_cpu_fallback_in_product_path():

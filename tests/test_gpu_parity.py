@@ -173,7 +173,7 @@ def test_conv_layer(dev, case, B):
     """One fused conv+BN(+res)(+ReLU) layer through romp_conv_forward vs torch CPU conv2d."""
     import ctypes as C
     from romp_amd import lib as L
-    from romp_amd.plan import Program, Act
+    from romp_amd.plan import Program, Act, set_conv_math
     cin, cout, k, s, H, relu, use_res = case
     g = torch.Generator().manual_seed(cin * 1000 + cout + k + s + H)
     x = torch.randn(B, H, H, cin, generator=g)
@@ -190,7 +190,7 @@ def test_conv_layer(dev, case, B):
         ref = torch.relu(ref)
     ref = ref.permute(0, 2, 3, 1)
     P = Program(dev)
-    P.bf16x3 = True                      # pack the split weights too: bf16x3 variants join the sweep below
+    set_conv_math(P, 'all')              # pack the split weights too: bf16x3 and f16x2 variants join the sweep below
     xa = Act(0, cin, H, H, cin)
     P.buf_floats.append(cin * H * H)
     ra = None
@@ -276,23 +276,25 @@ def test_net_vs_oracle_batch(dev, net0):
     assert torch.equal(c1.unsqueeze(1), cm) and torch.equal(c2, c1)
 
 
-def test_net_bf16x3_parity(dev, golden_dir):
-    """conv_math='bf16x3': every conv the autotuner moves onto the bf16 matrix pipe (3-way split of both
-    operands, six piece products, f32 accumulation) must pass the SAME gates as the f32-MFMA network:
+@pytest.mark.parametrize('conv_math', ['bf16x3', 'f16x2'])
+def test_net_bf16x3_parity(dev, golden_dir, conv_math):
+    """conv_math='bf16x3' / 'f16x2': every conv the autotuner moves onto the 16-bit matrix pipe (3 bf16 pieces and six
+    piece products, or 2 fp16 pieces and three, f32 accumulation) must pass the SAME gates as the f32-MFMA network:
     1e-4 max-abs against the reference fixture and against the oracle."""
     from romp_amd.net import RompNet
     sd = O.make_romp_state_dict(0)
-    net = RompNet(sd, dev, max_batch=4, bf16x3=True)
+    net = RompNet(sd, dev, max_batch=4, bf16x3=conv_math)
     net.autotune(3, iters=1)
     names = net.variant_names(3)
-    n_bx3 = sum('bx3' in n for n in names)
-    print('convs on the bf16x3 kernels at B=3: %d of %d ops' % (n_bx3, len(names)))
+    tag = 'conv_bx' if conv_math == 'bf16x3' else 'conv_h2'
+    n_bx3 = sum(tag in n for n in names)
+    print('convs on the %s kernels at B=3: %d of %d ops' % (conv_math, n_bx3, len(names)))
     assert n_bx3 > 0
     img = O.make_images(3, seed=5)
     cm_o, pm_o = O.romp_net_forward(sd, img)
     cm, pm = net(img.to(dev))
     ec, ep = (cm.cpu() - cm_o).abs().max().item(), (pm.cpu() - pm_o).abs().max().item()
-    print(f'bf16x3 B=3 vs oracle: center {ec:.3e} params {ep:.3e}')
+    print(f'{conv_math} B=3 vs oracle: center {ec:.3e} params {ep:.3e}')
     assert ec < 1e-4 and ep < 1e-4
     g = _g(golden_dir, 'romp_net_b1.npz')
     net.autotune(1, iters=1)
@@ -300,7 +302,7 @@ def test_net_bf16x3_parity(dev, golden_dir):
     p = pm[0].reshape(145, -1).cpu().numpy()
     ec = np.abs(cm.cpu().numpy() - g['center_maps']).max()
     ep = np.abs(p[:, g['sample_pos']] - g['params_samples']).max()
-    print(f'bf16x3 B=1 vs reference fixture: center {ec:.3e} params {ep:.3e}')
+    print(f'{conv_math} B=1 vs reference fixture: center {ec:.3e} params {ep:.3e}')
     assert ec < 1e-4 and ep < 1e-4
 
 
@@ -349,6 +351,47 @@ def test_net_full_batch_properties(dev):
     cm2, pm2 = net.forward_nhwc(base[idx][perm])
     assert torch.equal(cm2, cm[perm]) and torch.equal(pm2, pm[perm])
     assert torch.isfinite(pm).all()
+
+
+@pytest.mark.parametrize('B,conv_math', [(32, 'f16x2'), (32, 'bf16x3'), (128, 'f16x2')])
+def test_net_benchmark_batch_vs_oracle(dev, B, conv_math):
+    """The sizes bench.py times (BASELINE configs[1]: B=32; the per-GPU shard of configs[2]: B=128), with the kernel
+    variants the autotuner picks AT THAT SIZE: images {0, 7, 19, B-1} of the batch against the oracle network (1e-4), and the
+    whole net -> parse -> SMPL result of those images against the oracle pipeline (detections exact, verts 1e-4 on
+    identical theta / beta, verts 1e-3 end to end)."""
+    import romp_amd
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh, settings.max_batch, settings.conv_math = 0, 1.3, B, conv_math
+    sd = O.make_romp_state_dict(0)
+    smpl_model = O.make_synthetic_smpl(0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
+    model.model.autotune(B, iters=1)
+    names = model.model.variant_names(B)
+    tag = 'conv_bx' if conv_math == 'bf16x3' else 'conv_h2'
+    assert sum(tag in n for n in names) > 0
+    img = O.make_images(B, seed=1)
+    x = img.to(dev)
+    cm, pm = model.model(x)
+    pick = [0, 7, 19, B - 1]
+    cm_o, pm_o = O.romp_net_forward(sd, img[pick])
+    ec = (cm[pick].cpu() - cm_o).abs().max().item()
+    ep = (pm[pick].cpu() - pm_o).abs().max().item()
+    print(f'B={B} {conv_math}: images {pick} vs oracle: center {ec:.3e} params {ep:.3e}')
+    assert ec < 1e-4 and ep < 1e-4
+    out, bids = model.forward_batch(x)
+    ref = O.parsing_outputs(cm_o.numpy(), pm_o.numpy(), settings.center_thresh)
+    assert out is not None and ref is not None
+    bids = bids.cpu().numpy()
+    rows = np.concatenate([np.nonzero(bids == b)[0] for b in pick])
+    assert np.array_equal(np.searchsorted(pick, bids[rows]), ref['batch_ids'])
+    assert np.array_equal(out['center_preds'].cpu().numpy()[rows], ref['center_preds'])
+    th, be = out['smpl_thetas'].cpu().numpy()[rows], out['smpl_betas'].cpu().numpy()[rows]
+    vo, jo, _ = O.smpl_forward(smpl_model, be, th)                                       # identical theta / beta
+    ev = np.abs(out['verts'].cpu().numpy()[rows] - vo).max()
+    vr, _, _ = O.smpl_forward(smpl_model, ref['smpl_betas'], ref['smpl_thetas'])       # the oracle's own theta / beta
+    ee = np.abs(out['verts'].cpu().numpy()[rows] - vr).max()
+    print(f'B={B} {conv_math}: {len(rows)} persons in the 4 images; verts max-abs {ev:.3e} (same theta), {ee:.3e} (end to end)')
+    assert ev < 1e-4 and ee < 1e-3
 
 
 # ------------------------------------------------------------------------------ end to end
