@@ -53,6 +53,13 @@ const char* romp_last_error(void);
 #define ROMP_BUF_CENTER  (-3)   /* forward()'s center_maps out (B,64,64)                  */
 #define ROMP_BUF_PARAMS  (-4)   /* forward()'s params_maps out (B,64,64,145) NHWC         */
 
+/* Activation tensor formats.  F32: NHWC float32.  H2: the same addressing, but every channel octet (32 bytes) holds eight
+ * high fp16 pieces then eight low fp16 pieces of x * 2^act_shift (x = (h1 + h2) * 2^-act_shift up to 2^-22 relative): what the
+ * f16x2 conv kernels compute with, stored once by the producer instead of being re-split by every consumer (plan.py decides per
+ * tensor; channel strides / offsets of an H2 tensor are multiples of 8). */
+#define ROMP_FMT_F32     0
+#define ROMP_FMT_H2      1
+
 #define ROMP_OP_STEM      1     /* x/255*2-1 + conv3x3 s2 (Cin=3) + BN + ReLU  (model.py:384-387) */
 #define ROMP_OP_CONV      2     /* conv KxK (K=1|3, stride 1|2) + scale/shift (+res) (+ReLU)      */
 #define ROMP_OP_FUSESUM   3     /* y = relu(sum_t up_nearest(T_t))   (model.py:233-244)           */
@@ -89,6 +96,8 @@ typedef struct romp_op {
                                      ksize 2 (one output parity of ConvTranspose2d k4 s2 p1): 1 or 0               */
     int32_t out_rstride, out_bstride;  /* CONV: output row / image stride in floats; 0 = dense (Wo*out_cstride,
                                      Ho*Wo*out_cstride).  Sparse strides interleave the parity outputs of a transposed conv */
+    int32_t in_fmt, out_fmt, res_fmt;   /* CONV / STEM / FUSESUM (out_fmt): ROMP_FMT_F32 or ROMP_FMT_H2 */
+    int32_t term_fmt[4];          /* FUSESUM: format of each term */
     int32_t act_shift;            /* CONV, f16x2 kernels: activations are multiplied by 2^act_shift before they are split
                                      into fp16 pieces (keeps the low piece out of the fp16 subnormal range; |x| must stay
                                      below 65504 / 2^act_shift).  scale_h2 carries the inverse.                       */
@@ -146,6 +155,10 @@ void romp_net_destroy(romp_net* net);
 int  romp_conv_forward(const romp_op* op_host, const float* in, const float* res, float* out,
                        int B, int mode, int variant, void* stream);
 int  romp_conv_num_variants(void);
+/* Developer aid: with env ROMP_CONV_TRACE=1 the split-precision conv kernels stamp their phases (s_memtime) per wave;
+ * copies the stamps of the most recent launch (64 words per wave: count, then (time << 8 | event)) to the host and
+ * returns the number of words, or < 0.  Synchronises the device. */
+int  romp_conv_trace_read(unsigned long long* dst_host, int max_words);
 
 /* Name of kernel variant `variant` (or, if < 0, of the heuristic choice at batch B) for `op`;
  * ROMP_EINVAL if that variant cannot run this op. */

@@ -62,6 +62,7 @@ def build_bev_hrnet32(sd, device, input_size=512, bf16x3=False) -> Program:
     # conv2 + bn2 + residual + ReLU as a 2-group conv; output persistent (param_head features are
     # read by romp_bev_regress after the program finished)
     P.fv_buf = P.alloc(256 * MAP * MAP, persistent=True)
+    P.exported_bufs.add(P.fv_buf)
     y = Act(P.fv_buf, 256, MAP, MAP, 256)
     P.conv('bev.heads.conv2', t, [sd[f'{h}.0.0.conv2.weight'] for h in heads], [bn(f'{h}.0.0.bn2', 128)[0] for h in heads],
            [bn(f'{h}.0.0.bn2', 128)[1] for h in heads], 3, 1, True, res=r, out=y, groups=2)

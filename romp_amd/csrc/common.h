@@ -38,14 +38,15 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
                 int mode, int variant, int* queue, hipStream_t st, int wg_cap = 0);
 int describe_conv(const romp_op& op, int B, int variant, char* out, int n);
 int conv_num_variants();
+int conv_trace_read(unsigned long long* dst_host, int max_words);
 int conv_init();
 bool conv_variant_valid(const romp_op& op, int variant);
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
 int launch_stem7(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
 int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStream_t st);
-struct FuseTerm { const float* ptr; int shift; int cstride; };
+struct FuseTerm { const float* ptr; int shift; int cstride; int fmt; };
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
-                   int out_cstride, int out_coff, int relu, hipStream_t st);
+                   int out_cstride, int out_coff, int relu, hipStream_t st, int out_fmt = 0, int act_shift = 0);
 
 // BEV head pieces (bev.hip); *_host pointers are dereferenced on the host at launch time
 int launch_bev_pack(const float* fv, int fv_cs, const float* feats, int f_cs, float* out, int B, hipStream_t st);

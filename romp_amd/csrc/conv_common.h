@@ -15,6 +15,8 @@ struct ConvParams {
     const uint4* wh;          // f16x2-split weights (conv_h2 / conv_h2d kernels), or nullptr
     const float* scale_h;     // their epilogue scale (scale / (weight scale * act_scale))
     float act_scale;          // 2^act_shift, applied to the activations before the fp16 split
+    float inv_act_scale;      // 2^-act_shift
+    int in_h2, out_h2, res_h2;   // tensor formats: 0 = NHWC float32, 1 = H2 (pre-split fp16 pieces, see h2_pack below)
     int* queue;               // 8 per-XCD work counters, QUEUE_STRIDE ints apart, zeroed before the launch
     int H, W, Ho, Wo;
     int Cout;                 // valid output channels per group (store mask)
@@ -31,6 +33,8 @@ struct ConvParams {
     int w_gs;                 // floats per group in the packed weight
     int pad_h, pad_w;         // rows / columns of zero padding before the first tap
     int out_rs, out_bs;       // output row stride / image stride in floats (dense: Wo*out_cs, Ho*Wo*out_cs)
+    unsigned long long* trace;   // nullptr, or TRACE_SLOTS words per wave: (s_memtime << 8 | event code) stamps (env ROMP_CONV_TRACE=1;
+                                 // split-precision kernels only; read back with romp_conv_trace_read, scripts/conv_trace.py)
     int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
                               // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
@@ -38,6 +42,31 @@ struct ConvParams {
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- the H2 activation format -------------------------------------------------------------------------------------
+// An activation tensor the f16x2 kernels consume can live in HBM already split: per pixel and channel OCTET o (channels
+// 8o..8o+7) one 16-byte unit with the eight HIGH fp16 pieces h1 followed by one with the eight LOW pieces h2, where
+// x * 2^act_shift = h1 + h2 (up to 2^-22 relative).  An octet occupies the 32 bytes its eight floats would, so channel
+// strides / offsets (multiples of 8) and every address computation are those of the float32 tensor.  Consumers copy the
+// units to LDS as they are (no conversion work, and they can be moved by LDS-DMA); producers split once in their
+// epilogue; residual adds and fuse sums use h1 + h2 (22 significant bits: 2^-23 relative, f32 rounding class).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo) {
+    const float x[4] = {v.x * act_scale, v.y * act_scale, v.z * act_scale, v.w * act_scale};
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)x[e];                       // round to nearest even
+        l[e] = (_Float16)(x[e] - (float)h[e]);       // the subtraction is exact
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+__device__ __forceinline__ float4 h2_unpack(uint2 hi, uint2 lo, float inv_act_scale) {
+    const f16x4 h = __builtin_bit_cast(f16x4, hi), l = __builtin_bit_cast(f16x4, lo);
+    return make_float4(((float)h[0] + (float)l[0]) * inv_act_scale, ((float)h[1] + (float)l[1]) * inv_act_scale,
+                       ((float)h[2] + (float)l[2]) * inv_act_scale, ((float)h[3] + (float)l[3]) * inv_act_scale);
+}
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 struct ConvCfg {
@@ -61,6 +90,21 @@ struct ConvCfg {
 };
 
 struct Item { int b, ty, tx, n0, g; };
+
+constexpr int TRACE_SLOTS = 64, TRACE_WAVES = 4096;
+// one stamp per wave (lane 0): word 0 of the wave's slot block counts the stamps, words 1.. hold them
+#define ROMP_TRACE(code)                                                                             \
+    do {                                                                                             \
+        if (p.trace) {                                                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                              \
+            const unsigned w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                 \
+            if ((threadIdx.x & 63) == 0 && w_ < (unsigned)TRACE_WAVES && tr_n < TRACE_SLOTS - 1) {   \
+                p.trace[(size_t)w_ * TRACE_SLOTS + 1 + tr_n] = (t_ << 8) | (unsigned)(code);         \
+                p.trace[(size_t)w_ * TRACE_SLOTS] = (unsigned long long)(tr_n + 1);                  \
+            }                                                                                        \
+            ++tr_n;                                                                                  \
+        }                                                                                            \
+    } while (0)
 
 __device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, int NW) {
     const int s = j % p.ns_total, tl = j / p.ns_total;
@@ -98,7 +142,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
     }
     if (p.vec_io) {
         float4 r[MT][NT][4];
-        if (res) {
+        if (res && p.res_h2) {
+            // H2 residual: this lane's 4 channels are half an octet: 8 bytes of the high unit and 8 of the low unit
+            uint2 rh[MT][NT][4], rl[MT][NT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const char* rp = reinterpret_cast<const char*>(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8))) + lh * 8;
+                        rh[m][n][g4] = *reinterpret_cast<const uint2*>(rp);
+                        rl[m][n][g4] = *reinterpret_cast<const uint2*>(rp + 16);
+                    }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) r[m][n][g4] = h2_unpack(rh[m][n][g4], rl[m][n][g4], p.inv_act_scale);
+        } else if (res) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -128,7 +191,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                     v.y = fmaxf(fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y) + r[m][n][g4].y, floor_v);
                     v.z = fmaxf(fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z) + r[m][n][g4].z, floor_v);
                     v.w = fmaxf(fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w) + r[m][n][g4].w, floor_v);
-                    if (rowok[m]) *reinterpret_cast<float4*>(out + (outo[m] + (unsigned)(cur.n0 + cl))) = v;
+                    if (p.out_h2) {
+                        uint2 hi, lo;
+                        h2_pack(v, p.act_scale, hi, lo);
+                        char* op_ = reinterpret_cast<char*>(out + (outo[m] + (unsigned)(cur.n0 + n * 32 + g4 * 8))) + lh * 8;
+                        if (rowok[m]) {
+                            *reinterpret_cast<uint2*>(op_) = hi;
+                            *reinterpret_cast<uint2*>(op_ + 16) = lo;
+                        }
+                    } else if (rowok[m]) {
+                        *reinterpret_cast<float4*>(out + (outo[m] + (unsigned)(cur.n0 + cl))) = v;
+                    }
                 }
             }
     } else {

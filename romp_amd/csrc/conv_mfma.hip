@@ -51,6 +51,7 @@ static void collect_variants() {
 static bool g_attr_done = false;
 static int g_num_cu = 256;
 static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers without an arena
+static unsigned long long* g_trace = nullptr;   // env ROMP_CONV_TRACE=1: per-wave phase stamps of the most recent split-precision conv launch
 
 static const int kMaxLds = 160 * 1024;
 
@@ -73,6 +74,8 @@ static int ensure_attrs() {
         kVariants[i].occ = occ > 0 ? occ : 1;
     }
     ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, QUEUE_INTS * sizeof(int)));
+    { const char* e = getenv("ROMP_CONV_TRACE");
+      if (e && atoi(e)) ROMP_HIP_CHECK(hipMalloc((void**)&g_trace, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long))); }
     g_attr_done = true;
     return ROMP_OK;
 }
@@ -85,6 +88,8 @@ static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) 
     if (v.lds > kMaxLds) return false;
     if ((v.math == 1 || v.math == 2) && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.math >= 3 && (op.weight_h2 == nullptr || op.scale_h2 == nullptr || (op.cin_pad & 15))) return false;
+    if (op.in_fmt == ROMP_FMT_H2 && v.math < 3) return false;          // only the f16x2 kernels stage pre-split activations
+    if ((op.out_fmt == ROMP_FMT_H2 || op.res_fmt == ROMP_FMT_H2) && !(op.Cout == op.cout_pad)) return false;   // vector epilogue only
     if (v.ks != op.ksize || v.s != op.stride) return false;
     if (Wo % v.tw) return false;                     // rows may be partial (masked), columns may not
     if (op.cin_pad % v.ck || op.cout_pad % (v.nt * 32)) return false;
@@ -97,7 +102,8 @@ static int choose_variant(const romp_op& op, int Ho, int Wo, int B) {
     double best_score = -1;
     for (int i = 0; i < kNumVariants; ++i) {
         const ConvVariant& v = kVariants[i];
-        if (!variant_ok(v, op, Ho, Wo) || v.math) continue;     // bf16x3 variants are chosen by autotune / explicitly
+        if (!variant_ok(v, op, Ho, Wo)) continue;
+        if (v.math && op.in_fmt != ROMP_FMT_H2) continue;       // split-precision variants are chosen by autotune / explicitly (H2 input: they are the only ones)
         const long items = (long)B * ((Ho + v.th - 1) / v.th) * (Wo / v.tw) * (op.cout_pad / (v.nt * 32)) * op.groups;
         const double eff = (double)Ho / (((Ho + v.th - 1) / v.th) * v.th);   // partial row tiles waste MFMA work
         double fill = items >= 512 ? 1.0 : (double)items / 512.0;
@@ -137,6 +143,14 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.wh = reinterpret_cast<const uint4*>(op.weight_h2);
     p.scale_h = op.scale_h2;
     p.act_scale = ldexpf(1.f, op.act_shift);
+    p.inv_act_scale = ldexpf(1.f, -op.act_shift);
+    p.in_h2 = op.in_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.res_h2 = res && op.res_fmt == ROMP_FMT_H2;
+    if (p.in_h2 || p.out_h2 || p.res_h2) {
+        ROMP_REQUIRE(mode == 0, "conv: the naive cross-check kernel only handles float32 tensors");
+        ROMP_REQUIRE(((op.in_cstride | op.in_coff | op.in_gstride) & 7) == 0 || !p.in_h2, "conv: H2 input needs octet-aligned channels");
+        ROMP_REQUIRE(((op.out_cstride | op.out_coff | op.out_gstride | op.Cout) & 7) == 0 || !p.out_h2, "conv: H2 output needs octet-aligned channels");
+        ROMP_REQUIRE(((op.res_cstride | op.res_coff | op.res_gstride) & 7) == 0 || !p.res_h2, "conv: H2 residual needs octet-aligned channels");
+    }
     p.H = op.H; p.W = op.W;
     out_dims(op, &p.Ho, &p.Wo);
     p.Cout = op.Cout; p.cin_valid = op.Cin; p.cin_pad = op.cin_pad; p.cout_pad = op.cout_pad;
@@ -154,8 +168,10 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.nslices = p.ns_total = p.n_queues = p.per_queue = 1;
     p.queue = nullptr;
     { const char* e = getenv("ROMP_CONV_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.trace = nullptr;
     p.vec_io = (op.Cout == op.cout_pad && (op.Cout & 3) == 0 && (op.out_cstride & 3) == 0 && (op.out_coff & 3) == 0 && (op.out_gstride & 3) == 0 &&
                 (!res || ((op.res_cstride & 3) == 0 && (op.res_coff & 3) == 0 && (op.res_gstride & 3) == 0))) ? 1 : 0;
+    ROMP_REQUIRE(p.vec_io || !(p.out_h2 || p.res_h2), "conv: H2 output / residual needs the vector epilogue (Cout %d, pad %d)", op.Cout, op.cout_pad);
     if (mode == 1) {
         const size_t total = (size_t)B * p.Ho * p.Wo * op.Cout * op.groups;
         int blocks = (int)((total + 255) / 256);
@@ -188,9 +204,21 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     const long want = v.pp ? (items + 1) / 2 : items;         // a ping-pong workgroup runs two item streams
     if (grid > want) grid = want;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;    // same number of workgroups per queue
+    if (g_trace) {
+        p.trace = g_trace;
+        ROMP_HIP_CHECK(hipMemsetAsync(g_trace, 0, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long), st));
+    }
     hipLaunchKernelGGL(v.fn, dim3((unsigned)grid), dim3(v.pp ? 512 : 256), v.lds, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
+}
+
+int conv_trace_read(unsigned long long* dst_host, int max_words) {
+    ROMP_REQUIRE(g_trace != nullptr, "conv trace is off (set ROMP_CONV_TRACE=1 before the first launch)");
+    const int n = max_words < TRACE_WAVES * TRACE_SLOTS ? max_words : TRACE_WAVES * TRACE_SLOTS;
+    ROMP_HIP_CHECK(hipDeviceSynchronize());
+    ROMP_HIP_CHECK(hipMemcpy(dst_host, g_trace, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {

@@ -130,9 +130,18 @@ struct SplitCfg {
     static constexpr int LDS_BYTES_DMA = A_BYTES + 2 * SUB_UNITS * 16 + 4 * C::NW * 4 + 32;
 };
 
-// staging registers of one float4 of activations -> NP pieces in LDS
+// LDS layout of a pixel's chunk.  bf16x3: [piece][CK channels].  f16x2: the H2 order, [octet][piece][8 channels], so that a
+// tensor stored in the H2 format (conv_common.h) is staged by plain 16-byte copies.
 template <int NP, int CK>
-__device__ __forceinline__ void write_pieces(char* dst, float4 av, float act_scale) {
+__device__ __forceinline__ constexpr int frag_off(int k16, int pc) {         // + frag_lane<NP>(lh): this lane's k-half
+    return NP == 2 ? k16 * 64 + pc * 16 : pc * (CK * 2) + k16 * 32;
+}
+template <int NP>
+__device__ __forceinline__ constexpr int frag_lane(int lh) { return NP == 2 ? lh * 32 : lh * 16; }
+
+// staging registers of one float4 of float32 activations (channels 4*qq .. 4*qq+3 of the chunk) -> NP pieces in LDS
+template <int NP, int CK>
+__device__ __forceinline__ void write_pieces(char* pix, int qq, float4 av, float act_scale) {
     unsigned short h[4][NP];
     if (NP == 2) { av.x *= act_scale; av.y *= act_scale; av.z *= act_scale; av.w *= act_scale; }
     Piece<NP>::split(av.x, h[0]);
@@ -144,7 +153,8 @@ __device__ __forceinline__ void write_pieces(char* dst, float4 av, float act_sca
         uint2 u;
         u.x = (unsigned)h[0][pc] | ((unsigned)h[1][pc] << 16);
         u.y = (unsigned)h[2][pc] | ((unsigned)h[3][pc] << 16);
-        *reinterpret_cast<uint2*>(dst + pc * (CK * 2)) = u;
+        char* dst = NP == 2 ? pix + (qq >> 1) * 32 + pc * 16 + (qq & 1) * 8 : pix + qq * 8 + pc * (CK * 2);
+        *reinterpret_cast<uint2*>(dst) = u;
     }
 }
 
@@ -164,7 +174,7 @@ __device__ __forceinline__ void mma_stage_split(const char* sA, const char* sB, 
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int pc = 0; pc < NP; ++pc)
-                xf[buf][m][pc] = *reinterpret_cast<const frag*>(sA + xoff[m] + dy * X::ROWB + dx * X::PSB + pc * (CK * 2) + k16 * 32);
+                xf[buf][m][pc] = *reinterpret_cast<const frag*>(sA + xoff[m] + dy * X::ROWB + dx * X::PSB + frag_off<NP, CK>(k16, pc));
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -233,7 +243,8 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
             const int qq = idc % C::QC, pix = idc / C::QC;
             const int hx = pix % C::HC, hy = pix / C::HC;
             const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
-            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid;
+            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
+                            ((NP == 2 && p.in_h2) ? c0 + (qq >> 1) * 8 : c) < p.cin_valid;     // H2: unit qq = piece (qq & 1) of octet qq >> 1
             ra[k] = ldg4(in + (ok ? (unsigned)((iy * p.W + ix) * p.in_cs + c) : 0u));
             ra_ok = k == 0 ? (ok ? 1u : 0u) : (ra_ok | ((ok ? 1u : 0u) << k));
         }
@@ -266,7 +277,9 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
             if (idx < C::A_VEC) {
                 const int qq = idx % C::QC, pix = idx / C::QC;
                 const float4 av = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                write_pieces<NP, CK>(sA + (pix / C::HC) * X::ROWB + (pix % C::HC) * X::PSB + qq * 8, av, p.act_scale);
+                char* pixp = sA + (pix / C::HC) * X::ROWB + (pix % C::HC) * X::PSB;
+                if (NP == 2 && p.in_h2) *reinterpret_cast<float4*>(pixp + qq * 16) = av;       // already split: a plain copy
+                else write_pieces<NP, CK>(pixp, qq, av, p.act_scale);
             }
         }
 #pragma unroll
@@ -282,14 +295,19 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
     for (int m = 0; m < MT; ++m) {
         const int mb = wave * MT + m;
         const int row = mb * C::RPB + li / TW, col = li % TW;
-        xoff[m] = (row * S) * X::ROWB + (col * S) * X::PSB + lh * 16;
+        xoff[m] = (row * S) * X::ROWB + (col * S) * X::PSB + frag_lane<NP>(lh);
     }
     const int woff = (lh * C::NW + li) * 16;
 
+    int tr_n = 0;
+    ROMP_TRACE(1);                                     // kernel entry
     Item cur = decode_item(p, q, j_cur, C::NW);
     issue_loads(cur, 0);
+    ROMP_TRACE(2);                                     // first loads issued
     write_lds(true, 0);
+    ROMP_TRACE(3);                                     // first stage written to LDS (the loads have landed)
     __syncthreads();                                   // stage 0 in LDS; also publishes sQ[1]
+    ROMP_TRACE(4);
     int j_next = sQ[1];
     int slot = 0, ch = 0;
     Item nxt = cur;
@@ -313,12 +331,17 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
         const int c0 = last ? 0 : (ch + 1) * CK;
         if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
         if (pf && !(p.dbg & 1)) issue_loads(tgt, c0);
+        ROMP_TRACE(10);                                // stage start: next loads issued
         if (!(p.dbg & 8)) mma_stage_split<NP, KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
+        ROMP_TRACE(11);                                // MFMA block done
         if (ch == 0 && tid == 0) sQ[0] = j_after;
         __syncthreads();
+        ROMP_TRACE(12);                                // barrier: all waves done reading
         if (pf && !(p.dbg & 2)) write_lds(last, slot ^ 1);
+        ROMP_TRACE(13);                                // next stage written to LDS
         if (last) {
             if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+            ROMP_TRACE(14);                            // epilogue issued
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -328,6 +351,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
         }
         if (last && !have_next) break;
         __syncthreads();
+        ROMP_TRACE(15);                                // barrier: next stage visible
         if (last) {
             cur = nxt;
             slot ^= 1;
@@ -418,7 +442,8 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
             const int qq = idc % C::QC, pix = idc / C::QC;
             const int hx = pix % C::HC, hy = pix / C::HC;
             const int iy = iy0 + hy, ix = ix0 + hx, c = c0 + qq * 4;
-            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.cin_valid;
+            const bool ok = idx < C::A_VEC && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
+                            ((NP == 2 && p.in_h2) ? c0 + (qq >> 1) * 8 : c) < p.cin_valid;     // H2: unit qq = piece (qq & 1) of octet qq >> 1
             ra[k] = ldg4(in + (ok ? (unsigned)((iy * p.W + ix) * p.in_cs + c) : 0u));
             ra_ok = k == 0 ? (ok ? 1u : 0u) : (ra_ok | ((ok ? 1u : 0u) << k));
         }
@@ -434,7 +459,9 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
             if (idx < C::A_VEC) {
                 const int qq = idx % C::QC, pix = idx / C::QC;
                 const float4 av = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                write_pieces<NP, CK>(sA + (pix / C::HC) * X::ROWB + (pix % C::HC) * X::PSB + qq * 8, av, p.act_scale);
+                char* pixp = sA + (pix / C::HC) * X::ROWB + (pix % C::HC) * X::PSB;
+                if (NP == 2 && p.in_h2) *reinterpret_cast<float4*>(pixp + qq * 16) = av;       // already split: a plain copy
+                else write_pieces<NP, CK>(pixp, qq, av, p.act_scale);
             }
         }
         if (first_chunk && tid < 2 * C::NW) sS[slot * 2 * C::NW + tid] = rs;
@@ -445,16 +472,21 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
     for (int m = 0; m < MT; ++m) {
         const int mb = wave * MT + m;
         const int row = mb * C::RPB + li / TW, col = li % TW;
-        xoff[m] = (row * S) * X::ROWB + (col * S) * X::PSB + lh * 16;
+        xoff[m] = (row * S) * X::ROWB + (col * S) * X::PSB + frag_lane<NP>(lh);
     }
     const int woff = (lh * C::NW + li) * 16;
 
+    int tr_n = 0;
+    ROMP_TRACE(1);
     Item cur = decode_item(p, q, j_cur, C::NW);
     issue_B(cur, 0, 0, 0);
     issue_A(cur, 0);
+    ROMP_TRACE(2);
     write_A(true, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ROMP_TRACE(3);
     __syncthreads();                                   // stage 0 in LDS; also publishes sQ[1]
+    ROMP_TRACE(4);
     int j_next = sQ[1];
     int slot = 0, ch = 0, row = 0, bbuf = 0, par = 0;
     Item nxt = cur;
@@ -485,6 +517,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
         const bool pfA = last_row && pfB;                          // next chunk's pixels: loaded under the last tap row
         if (pfA && !(p.dbg & (1 | 64))) issue_A(tgtB, c0B);
         __builtin_amdgcn_sched_barrier(0);               // keep every DMA / load issue ABOVE the MFMA block (hipcc sank 3 of the 5 DMAs below it)
+        ROMP_TRACE(10);
         if (!(p.dbg & 8)) {
             const char* sBc = sB + bbuf * (X::SUB_UNITS * 16);
 #pragma unroll
@@ -496,7 +529,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int pc = 0; pc < NP; ++pc)
-                            xf[m][pc] = *reinterpret_cast<const frag*>(sA + xoff[m] + row * X::ROWB + dx * X::PSB + pc * (CK * 2) + k16 * 32);
+                            xf[m][pc] = *reinterpret_cast<const frag*>(sA + xoff[m] + row * X::ROWB + dx * X::PSB + frag_off<NP, CK>(k16, pc));
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -508,14 +541,19 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
                         for (int n = 0; n < NT; ++n) acc[m][n] = Piece<NP>::mma(wf[n], xf[m], acc[m][n]);
                 }
         }
+        ROMP_TRACE(11);
         if (ch == 0 && row == 0 && tid == 0) sQ[2 + par] = j_after;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA has landed (and ra is in)
+        ROMP_TRACE(16);                                            // DMA / loads landed
         __syncthreads();                                           // all waves: done reading bbuf / sA, DMA visible
+        ROMP_TRACE(12);
         bbuf ^= 1;
         if (last_row) {
             if (pfA && !(p.dbg & 2)) write_A(last_ch, slot ^ 1);
+            ROMP_TRACE(13);
             if (last_ch) {
                 if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+                ROMP_TRACE(14);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -525,6 +563,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
                 if (!have_next) break;
             }
             __syncthreads();                                       // next chunk's pixels visible
+            ROMP_TRACE(15);
             row = 0;
             if (last_ch) {
                 cur = nxt;

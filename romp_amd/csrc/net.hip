@@ -146,10 +146,11 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
                 ROMP_REQUIRE(t[k].ptr, "fusesum: bad term buffer %d", op.term_buf[k]);
                 t[k].shift = op.term_shift[k];
                 t[k].cstride = op.term_cstride[k];
+                t[k].fmt = op.term_fmt[k];
             }
             float* out = resolve_out(n, op.out_buf, center, params);
             ROMP_REQUIRE(out, "fusesum: bad out buffer %d", op.out_buf);
-            return launch_fusesum(t, op.n_terms, out, B, op.H, op.W, op.Cout, op.out_cstride, op.out_coff, op.relu, st);
+            return launch_fusesum(t, op.n_terms, out, B, op.H, op.W, op.Cout, op.out_cstride, op.out_coff, op.relu, st, op.out_fmt, op.act_shift);
         }
         case ROMP_OP_FORK:
         case ROMP_OP_JOIN:
@@ -513,6 +514,8 @@ int romp_conv_forward(const romp_op* op, const float* in, const float* res, floa
 }
 
 int romp_conv_num_variants(void) { return conv_num_variants(); }
+
+int romp_conv_trace_read(unsigned long long* dst_host, int max_words) { return conv_trace_read(dst_host, max_words); }
 
 int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) {
     ROMP_REQUIRE(op && out && n > 0 && B > 0, "romp_conv_describe: bad arguments");

@@ -6,13 +6,14 @@
 //   * fuse-sum: y_i = relu(sum_j up_nearest(T_j))  (HighResolutionModule.forward model.py:233-244)
 //     -- replaces the reference's nearest-upsample kernels and the chain of adds with one pass that
 //     reads each term once and writes y once.  Summation order is the reference's (j ascending).
-#include "common.h"
+#include "conv_common.h"      // h2_pack / h2_unpack: the H2 activation format
 
 namespace romp {
 
 struct StemParams {
     const float* image; const float* w; const float* scale; const float* shift; float* out;
     int H, W, Ho, Wo, out_cs, out_co, tiles_x, tiles_y;
+    int out_h2; float act_scale;      // output in the H2 format (conv_common.h)
 };
 
 // packed stem weight: [tap 9][cin 3][cout 64]
@@ -81,7 +82,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
         float4 v;
         v.x = fmaxf(fmaf(acc[t].x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(acc[t].y, sc.y, sh.y), 0.f);
         v.z = fmaxf(fmaf(acc[t].z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(acc[t].w, sc.w, sh.w), 0.f);
-        *reinterpret_cast<float4*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + cg * 4) = v;
+        if (p.out_h2) {                                   // channels 4cg..4cg+3 = half (cg & 1) of octet cg >> 1
+            uint2 hi, lo;
+            h2_pack(v, p.act_scale, hi, lo);
+            char* o = reinterpret_cast<char*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + (cg >> 1) * 8) + (cg & 1) * 8;
+            *reinterpret_cast<uint2*>(o) = hi;
+            *reinterpret_cast<uint2*>(o + 16) = lo;
+        } else {
+            *reinterpret_cast<float4*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + cg * 4) = v;
+        }
     }
 }
 
@@ -93,6 +102,8 @@ int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStr
     p.image = image; p.w = op.weight; p.scale = op.scale; p.shift = op.shift; p.out = out;
     p.H = op.H; p.W = op.W; p.Ho = op.H / 2; p.Wo = op.W / 2;
     p.out_cs = op.out_cstride; p.out_co = op.out_coff;
+    p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.act_scale = ldexpf(1.f, op.act_shift);
+    ROMP_REQUIRE(!p.out_h2 || ((op.out_cstride | op.out_coff) & 7) == 0, "stem: H2 output needs octet-aligned channels");
     p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 16;
     hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
@@ -228,48 +239,82 @@ int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStr
 }
 
 struct FuseParams {
-    const float* t[4]; int shift[4]; int cs[4];
-    float* out; int n_terms, H, W, C4, out_cs, out_co, relu; size_t total;
+    const float* t[4]; int shift[4]; int cs[4]; int h2[4];
+    float* out; int n_terms, H, W, C8, out_cs, out_co, relu, out_h2; float act_scale, inv_act_scale; size_t total;
 };
 
+// One thread per pixel and channel OCTET (32 bytes in either format).  H2 terms are summed in the scaled domain
+// (x * 2^act_shift: exact, a power of two commutes with every f32 rounding), float32 terms are scaled on the way in.
 __global__ __launch_bounds__(256) void fusesum_kernel(FuseParams p) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
-        const int c = (int)(r % p.C4) * 4; r /= p.C4;
+        const int c = (int)(r % p.C8) * 8; r /= p.C8;
         const int x = (int)(r % p.W); r /= p.W;
         const int y = (int)(r % p.H);
         const int b = (int)(r / p.H);
-        float4 v;
+        float4 va, vb;                                 // channels c..c+3, c+4..c+7 (scaled by act_scale when any H2 is involved)
+        const bool scaled = p.out_h2 || p.h2[0] || p.h2[1] || p.h2[2] || p.h2[3];
+        const float in_scale = scaled ? p.act_scale : 1.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < p.n_terms) {
                 const int s = p.shift[k];
                 const int h = p.H >> s, w = p.W >> s;
-                const float4 tv = *reinterpret_cast<const float4*>(
-                    p.t[k] + (((size_t)b * h + (y >> s)) * w + (x >> s)) * p.cs[k] + c);
-                if (k == 0) v = tv;
-                else { v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w; }
+                const float* tp = p.t[k] + (((size_t)b * h + (y >> s)) * w + (x >> s)) * p.cs[k] + c;
+                const float4 u0 = *reinterpret_cast<const float4*>(tp), u1 = *reinterpret_cast<const float4*>(tp + 4);
+                float4 ta, tb;
+                if (p.h2[k]) {                         // u0 = eight high pieces, u1 = eight low pieces
+                    const uint4 hi = __builtin_bit_cast(uint4, u0), lo = __builtin_bit_cast(uint4, u1);
+                    ta = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), 1.f);
+                    tb = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), 1.f);
+                } else {
+                    ta = make_float4(u0.x * in_scale, u0.y * in_scale, u0.z * in_scale, u0.w * in_scale);
+                    tb = make_float4(u1.x * in_scale, u1.y * in_scale, u1.z * in_scale, u1.w * in_scale);
+                }
+                if (k == 0) { va = ta; vb = tb; }
+                else {
+                    va.x += ta.x; va.y += ta.y; va.z += ta.z; va.w += ta.w;
+                    vb.x += tb.x; vb.y += tb.y; vb.z += tb.z; vb.w += tb.w;
+                }
             }
         }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(p.out + (((size_t)b * p.H + y) * p.W + x) * p.out_cs + p.out_co + c) = v;
+        if (p.relu) {
+            va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+            vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+        }
+        float* op_ = p.out + (((size_t)b * p.H + y) * p.W + x) * p.out_cs + p.out_co + c;
+        if (p.out_h2) {
+            uint2 ha, la, hb, lb;
+            h2_pack(va, 1.f, ha, la);
+            h2_pack(vb, 1.f, hb, lb);
+            *reinterpret_cast<uint4*>(op_) = make_uint4(ha.x, ha.y, hb.x, hb.y);
+            *reinterpret_cast<uint4*>(op_ + 4) = make_uint4(la.x, la.y, lb.x, lb.y);
+        } else {
+            const float os = scaled ? p.inv_act_scale : 1.f;
+            *reinterpret_cast<float4*>(op_) = make_float4(va.x * os, va.y * os, va.z * os, va.w * os);
+            *reinterpret_cast<float4*>(op_ + 4) = make_float4(vb.x * os, vb.y * os, vb.z * os, vb.w * os);
+        }
     }
 }
 
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
-                   int out_cstride, int out_coff, int relu, hipStream_t st) {
+                   int out_cstride, int out_coff, int relu, hipStream_t st, int out_fmt, int act_shift) {
     ROMP_REQUIRE(n_terms >= 1 && n_terms <= 4, "fusesum: %d terms unsupported", n_terms);
-    ROMP_REQUIRE((C & 3) == 0 && (out_cstride & 3) == 0 && (out_coff & 3) == 0, "fusesum: channels must be float4 aligned");
+    ROMP_REQUIRE((C & 7) == 0 && (out_cstride & 3) == 0 && (out_coff & 3) == 0, "fusesum: channels must come in octets");
     FuseParams p;
-    for (int k = 0; k < 4; ++k) { p.t[k] = nullptr; p.shift[k] = 0; p.cs[k] = 0; }
+    for (int k = 0; k < 4; ++k) { p.t[k] = nullptr; p.shift[k] = 0; p.cs[k] = 0; p.h2[k] = 0; }
     for (int k = 0; k < n_terms; ++k) {
         ROMP_REQUIRE((terms[k].cstride & 3) == 0, "fusesum: term stride must be float4 aligned");
         ROMP_REQUIRE((H >> terms[k].shift) << terms[k].shift == H, "fusesum: term %d shift %d does not divide H", k, terms[k].shift);
-        p.t[k] = terms[k].ptr; p.shift[k] = terms[k].shift; p.cs[k] = terms[k].cstride;
+        ROMP_REQUIRE(terms[k].fmt != ROMP_FMT_H2 || (terms[k].cstride & 7) == 0, "fusesum: H2 term stride must be octet aligned");
+        p.t[k] = terms[k].ptr; p.shift[k] = terms[k].shift; p.cs[k] = terms[k].cstride; p.h2[k] = terms[k].fmt == ROMP_FMT_H2;
     }
-    p.out = out; p.n_terms = n_terms; p.H = H; p.W = W; p.C4 = C / 4;
+    p.out = out; p.n_terms = n_terms; p.H = H; p.W = W; p.C8 = C / 8;
     p.out_cs = out_cstride; p.out_co = out_coff; p.relu = relu;
-    p.total = (size_t)B * H * W * p.C4;
+    p.out_h2 = out_fmt == ROMP_FMT_H2;
+    ROMP_REQUIRE(!p.out_h2 || ((out_cstride | out_coff) & 7) == 0, "fusesum: H2 output needs octet-aligned channels");
+    p.act_scale = ldexpf(1.f, act_shift); p.inv_act_scale = ldexpf(1.f, -act_shift);
+    p.total = (size_t)B * H * W * p.C8;
     size_t blocks = (p.total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(fusesum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .plan import Program, build_romp_hrnet32, coord_channels
+from .plan import Program, build_romp_hrnet32, coord_channels, decode_h2, encode_h2
 
 
 class RompNet:
@@ -44,6 +44,8 @@ class RompNet:
             if self.program.coord_off is not None:      # ROMP head: constant CoordConv channels of the head input (model.py:473)
                 fs = input_size // 4
                 coords = coord_channels(self.max_batch, fs, self.device, self.program.head_in_ch, self.program.coord_off)
+                if self.program.buf_fmt.get(self.program.head_in_buf) == L.FMT_H2:     # the head input lives pre-split: constants too
+                    coords = encode_h2(coords.cpu()).to(self.device)
                 L.check(self.lib.romp_net_write_buffer(self._h, self.program.head_in_buf, L.ptr(coords),
                                                        coords.numel(), L.stream_ptr(self.device)))
             torch.cuda.synchronize(self.device)
@@ -126,10 +128,16 @@ class RompNet:
         """Device address of arena buffer `buf`."""
         return self.lib.romp_net_buffer_ptr(self._h, int(buf))
 
-    def read_buffer(self, buf, B):
+    def read_buffer(self, buf, B, channels=None):
+        """Debug / test helper: arena buffer `buf` of B images as float32 values.  A tensor stored in the H2 format is decoded
+        (`channels` = its channel stride, needed to find the octets)."""
         n = self.program.buf_floats[buf] * B
         out = torch.empty(n, device=self.device, dtype=torch.float32)
         L.check(self.lib.romp_net_read_buffer(self._h, buf, B, L.ptr(out), n, L.stream_ptr(self.device)))
+        if self.program.buf_fmt.get(buf) == L.FMT_H2:
+            assert channels is not None and channels % 8 == 0, 'H2 buffer: pass its channel stride'
+            torch.cuda.synchronize(self.device)
+            out = decode_h2(out.reshape(-1, channels)).reshape(-1)
         return out
 
     def profile(self, image, iters=3):

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, OP_CONV, OP_FORK,
+from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -131,6 +131,105 @@ def set_conv_math(P, conv_math):
     P.f16x2 = conv_math in ('f16x2', 'all')
 
 
+def encode_h2(x, act_shift=ACT_SHIFT):
+    """float32 (..., C) with C % 8 == 0 -> the H2 format (include/romp_hip.h ROMP_FMT_H2) as a float32-typed tensor of the same
+    shape: per channel octet eight high fp16 pieces then eight low pieces of x * 2^act_shift.  Host-side helper for constants
+    and tests (the kernels produce / consume the format themselves)."""
+    assert x.shape[-1] % 8 == 0
+    xs = x.float() * (2.0 ** act_shift)
+    h1 = xs.half()
+    h2 = (xs - h1.float()).half()
+    o = torch.stack([h1.reshape(*x.shape[:-1], -1, 8), h2.reshape(*x.shape[:-1], -1, 8)], -2)     # (..., C/8, 2, 8)
+    return o.contiguous().view(torch.float32).reshape(x.shape)
+
+
+def decode_h2(t, act_shift=ACT_SHIFT):
+    """Inverse of encode_h2 (to 22 significant bits): float32-typed H2 tensor (..., C) -> float32 values."""
+    h = t.contiguous().view(torch.float16).reshape(*t.shape[:-1], -1, 2, 8).float()
+    return ((h[..., 0, :] + h[..., 1, :]) * (2.0 ** -act_shift)).reshape(t.shape)
+
+
+def assign_formats(P):
+    """Decide per activation tensor whether it lives in HBM as float32 or already split (H2), and write the choice into the
+    ops.  A tensor (one live range of an arena buffer) is H2 iff conv_math offers the f16x2 kernels, every producer can write
+    H2 (vector-epilogue convs, stem, fuse sums) and every consumer reads it through an f16x2 kernel or a fuse sum; tensors
+    touched by anything else (max-pool, BEV head pieces, Conv1d, the host through romp_net_buffer_ptr) stay float32."""
+    P.buf_fmt = {}                                           # buffer -> format of its LAST live range (for read_buffer)
+    if not getattr(P, 'f16x2', False):
+        return
+    gens, cur = [], {}
+
+    def gen_for_write(buf):
+        g = cur.get(buf)
+        if g is None or gens[g]['read']:
+            gens.append(dict(buf=buf, ok=buf not in getattr(P, 'exported_bufs', ()), read=False, uses=[]))
+            cur[buf] = g = len(gens) - 1
+        return gens[g]
+
+    def gen_for_read(buf):
+        if buf not in cur:                                   # initialised from outside the program
+            gens.append(dict(buf=buf, ok=False, read=False, uses=[]))
+            cur[buf] = len(gens) - 1
+        g = gens[cur[buf]]
+        g['read'] = True
+        return g
+
+    def oct_ok(*v):
+        return all((int(x) & 7) == 0 for x in v)
+
+    for i, op in enumerate(P.ops):
+        if op.kind == OP_CONV:
+            h2_kernel = bool(op.weight_h2) and op.ksize != 13
+            if op.in_buf >= 0:
+                g = gen_for_read(op.in_buf)
+                g['uses'].append((i, 'in'))
+                g['ok'] &= h2_kernel and oct_ok(op.in_cstride, op.in_coff, op.in_gstride)
+            vec = op.Cout == op.cout_pad and oct_ok(op.Cout, op.out_cstride, op.out_coff, op.out_gstride) and op.ksize != 13
+            if op.res_buf >= 0:
+                g = gen_for_read(op.res_buf)
+                g['uses'].append((i, 'res'))
+                g['ok'] &= vec and oct_ok(op.res_cstride, op.res_coff, op.res_gstride)
+            if op.out_buf >= 0:
+                g = gen_for_write(op.out_buf)
+                g['uses'].append((i, 'out'))
+                g['ok'] &= vec
+        elif op.kind == OP_FUSESUM:
+            for k in range(op.n_terms):
+                g = gen_for_read(op.term_buf[k])
+                g['uses'].append((i, ('term', k)))
+                g['ok'] &= oct_ok(op.term_cstride[k])
+            g = gen_for_write(op.out_buf)
+            g['uses'].append((i, 'out'))
+            g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
+        elif op.kind == OP_STEM:
+            g = gen_for_write(op.out_buf)
+            g['uses'].append((i, 'out'))
+            g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
+        elif op.kind in (OP_FORK, OP_JOIN):
+            continue
+        else:                                                # any other op: its tensors stay float32
+            for b in (op.in_buf, op.res_buf):
+                if b >= 0:
+                    gen_for_read(b)['ok'] = False
+            for b in [op.out_buf] + ([op.term_buf[0]] if op.kind == OP_BEV_MAPS else []):     # BEV_MAPS has a second output
+                if b >= 0:
+                    gen_for_write(b)['ok'] = False
+    for g in gens:
+        fmt = FMT_H2 if (g['ok'] and any(r == 'out' for _, r in g['uses'])) else FMT_F32
+        P.buf_fmt[g['buf']] = fmt
+        for i, role in g['uses']:
+            op = P.ops[i]
+            op.act_shift = ACT_SHIFT
+            if role == 'in':
+                op.in_fmt = fmt
+            elif role == 'res':
+                op.res_fmt = fmt
+            elif role == 'out':
+                op.out_fmt = fmt
+            else:
+                op.term_fmt[role[1]] = fmt
+
+
 class Program:
     """The lowered network: ops (ctypes), packed constants (kept alive here), buffer sizes."""
 
@@ -151,6 +250,8 @@ class Program:
         self.f16x2 = False                                     # also pack f16x2-split weights (conv_h2 / conv_h2d kernels)
         self.conv_math = 'f32'
         self.persistent = set()
+        self.exported_bufs = set()                             # arena buffers the host reads through romp_net_buffer_ptr: float32
+        self.buf_fmt: Dict[int, int] = {}                      # filled by assign_formats
         self.head_in_buf: Optional[int] = None
         self.head_in_ch, self.coord_off = HEAD_IN_CH, None     # coord_off: first of the two constant CoordConv channels
 
@@ -314,6 +415,7 @@ class Program:
         return out
 
     def op_array(self):
+        assign_formats(self)
         arr = (RompOp * len(self.ops))()
         for i, o in enumerate(self.ops):
             arr[i] = o

@@ -1,5 +1,5 @@
 """Ablation timing of one conv layer (GPU): which part of the kernel costs what.
-usage: [ABLATE_KIND=mfma|bx3|bxd] [ABLATE_B=32] [ABLATE_DBG=0,4,...] python scripts/conv_ablate.py
+usage: [ABLATE_KIND=mfma|bx3|bxd|h2|h2d] [ABLATE_B=32] [ABLATE_DBG=0,4,...] python scripts/conv_ablate.py
 (prints a table; outputs are wrong under dbg flags -- bit meanings: ConvParams::dbg in csrc/conv_mfma.hip)"""
 import ctypes as C, os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 def run_case(case, B, variants, dbg):
     import torch
     from romp_amd import lib as L
-    from romp_amd.plan import Program, Act
+    from romp_amd.plan import Program, Act, set_conv_math
     cin, cout, k, s, H, use_res = case
     dev = torch.device('cuda:0')
     lib = L.load()
@@ -18,7 +18,7 @@ def run_case(case, B, variants, dbg):
     Ho = H // s
     res = torch.randn(B, Ho, Ho, cout, generator=g).to(dev) if use_res else None
     P = Program(dev)
-    P.bf16x3 = True
+    set_conv_math(P, 'all')
     P.buf_floats += [cin * H * H, cout * Ho * Ho]
     P.conv('t', Act(0, cin, H, H, cin), [w], [torch.ones(cout)], [torch.zeros(cout)], k, s, True,
            res=Act(1, cout, Ho, Ho, cout) if use_res else None)
@@ -53,11 +53,14 @@ if __name__ == '__main__':
             print('  dbg=%-3s %-36s %8.1f us %7.1f TF' % (os.environ.get('ROMP_CONV_DEBUG', '0'), name, us, tf))
         sys.exit(0)
     kind = os.environ.get('ABLATE_KIND', 'mfma')
-    cases = [((64, 64, 3, 1, 64, True), [kind + '_k3s1_mt2_nt2_tw16', kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt1_nt2_tw16']),
-             ((32, 32, 3, 1, 128, True), [kind + '_k3s1_mt2_nt1_tw16', kind + '_k3s1_mt2_nt1_tw32', kind + '_k3s1_mt1_nt1_tw32', kind + '_k3s1_mt1_nt1_tw16'])]
+    kinds = kind.split(',')
+    vs = lambda *tags: [k + '_' + t for k in kinds for t in tags]
+    cases = [((64, 64, 3, 1, 64, True), vs('k3s1_mt2_nt2_tw16_ck16', 'k3s1_mt2_nt1_tw16', 'k3s1_mt1_nt2_tw16')),
+             ((32, 32, 3, 1, 128, True), vs('k3s1_mt2_nt1_tw16', 'k3s1_mt2_nt1_tw32', 'k3s1_mt4_nt1_tw32', 'k3s1_mt1_nt1_tw16')),
+             ((128, 128, 3, 1, 32, True), vs('k3s1_mt2_nt2_tw16_ck16', 'k3s1_mt1_nt2_tw16'))]
     for case, variants in cases:
         print('case', case)
-        for dbg in [int(x) for x in os.environ.get('ABLATE_DBG', '0,4,1,2,3,7,16,23,8,12').split(',')]:
+        for dbg in [int(x) for x in os.environ.get('ABLATE_DBG', '0,32,15,7,8,4,3,12').split(',')]:
             env = dict(os.environ, ROMP_CONV_DEBUG=str(dbg))
             r = subprocess.run([sys.executable, __file__, 'child', json.dumps(case), json.dumps(variants)], env=env,
                                capture_output=True, text=True)

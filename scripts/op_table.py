@@ -1,19 +1,19 @@
 """Per-op table of the tuned network at batch B (GPU): variant, ms, GFLOP, TFLOP/s, algorithmic GB/s.
-usage: python scripts/op_table.py [B] [f32|bf16x3] [romp|bev]"""
+usage: python scripts/op_table.py [B] [f32|bf16x3|f16x2|all] [romp|bev]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from romp_amd import synthetic as S
 from romp_amd.net import RompNet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-math = sys.argv[2] if len(sys.argv) > 2 else 'bf16x3'
+math = sys.argv[2] if len(sys.argv) > 2 else 'f16x2'
 dev = torch.device('cuda:0')
 if len(sys.argv) > 3 and sys.argv[3] == 'bev':
     from romp_amd.bev_plan import build_bev_hrnet32
     net = RompNet(S.make_bev_state_dict(0), dev, max_batch=B, builder=build_bev_hrnet32,
-                  out_shapes=((64, 128, 128), (3, 64, 128, 128)), bf16x3=(math == 'bf16x3'))
+                  out_shapes=((64, 128, 128), (3, 64, 128, 128)), bf16x3=math)
 else:
-    net = RompNet(S.make_romp_state_dict(0), dev, max_batch=B, bf16x3=(math == 'bf16x3'))
+    net = RompNet(S.make_romp_state_dict(0), dev, max_batch=B, bf16x3=math)
 x = S.make_images(B, seed=1, device=dev)
 net.autotune(B)
 s = torch.cuda.Stream()

@@ -169,11 +169,14 @@ CONV_CASES = [
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'c%d_%d_k%d_s%d_h%d' % c[:5])
 @pytest.mark.parametrize('B', [1, 3])
-def test_conv_layer(dev, case, B):
-    """One fused conv+BN(+res)(+ReLU) layer through romp_conv_forward vs torch CPU conv2d."""
+@pytest.mark.parametrize('fmt', ['f32', 'h2'])
+def test_conv_layer(dev, case, B, fmt):
+    """One fused conv+BN(+res)(+ReLU) layer through romp_conv_forward vs torch CPU conv2d: the naive cross-check kernel, the
+    heuristic variant, then EVERY kernel variant able to run the layer.  fmt='h2': input / residual / output tensors in the
+    pre-split H2 format (only the f16x2 kernels read it; every kernel family's epilogue can write it)."""
     import ctypes as C
     from romp_amd import lib as L
-    from romp_amd.plan import Program, Act, set_conv_math
+    from romp_amd.plan import Program, Act, set_conv_math, encode_h2, decode_h2, ACT_SHIFT
     cin, cout, k, s, H, relu, use_res = case
     g = torch.Generator().manual_seed(cin * 1000 + cout + k + s + H)
     x = torch.randn(B, H, H, cin, generator=g)
@@ -199,24 +202,87 @@ def test_conv_layer(dev, case, B):
         ra = Act(1, cout, Ho, Ho, cout)
     P.conv('t', xa, [w], [scale], [shift], k, s, relu, res=ra)
     op = P.ops[0]
-    xd, rd = x.to(dev), (res.to(dev) if res is not None else None)
+    out_h2 = False
+    if fmt == 'h2':
+        if cin % 8 or not op.weight_h2:
+            pytest.skip('layer cannot read an H2 tensor (Cin %d)' % cin)
+        out_h2 = op.Cout == op.cout_pad and cout % 8 == 0
+        op.act_shift = ACT_SHIFT
+        op.in_fmt = L.FMT_H2
+        op.out_fmt = L.FMT_H2 if out_h2 else L.FMT_F32
+        op.res_fmt = L.FMT_H2 if (out_h2 and res is not None) else L.FMT_F32
+        x_in = encode_h2(x)
+        res_in = encode_h2(res) if (res is not None and op.res_fmt == L.FMT_H2) else res
+    else:
+        x_in, res_in = x, res
+    xd, rd = x_in.to(dev), (res_in.to(dev) if res_in is not None else None)
     lib = L.load()
     buf = C.create_string_buffer(128)
-    # naive cross-check kernel, the heuristic variant, then EVERY variant able to run this layer
-    runs = [(1, -1), (0, -1)] + [(0, v) for v in range(lib.romp_conv_num_variants())
-                                 if lib.romp_conv_describe(C.byref(op), B, v, buf, 128) == 0]
-    assert len(runs) >= 3
+    runs = ([(1, -1)] if fmt == 'f32' else []) + [(0, -1)] + [(0, v) for v in range(lib.romp_conv_num_variants())
+                                                                if lib.romp_conv_describe(C.byref(op), B, v, buf, 128) == 0]
+    assert len(runs) >= 2
     for mode, variant in runs:
         out = torch.full((B, Ho, Ho, cout), float('nan'), device=dev)
         L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), L.ptr(rd), L.ptr(out), B, mode, variant, L.stream_ptr(dev)))
         torch.cuda.synchronize()
-        err = (out.cpu() - ref).abs().max().item()
+        o = out.cpu()
+        if out_h2:
+            o = decode_h2(o)
+        err = (o - ref).abs().max().item()
         name = 'naive'
         if mode == 0:
             L.check(lib.romp_conv_describe(C.byref(op), B, variant, buf, 128))
             name = buf.value.decode()
-        print(f'{name} (variant {variant}): max-abs err {err:.3e} (ref absmax {ref.abs().max():.2f})')
+        print(f'{name} (variant {variant}, {fmt}): max-abs err {err:.3e} (ref absmax {ref.abs().max():.2f})')
         assert err < 3e-5, f'{name} err {err}'
+
+
+def test_fusesum_formats(dev):
+    """The fuse sum (model.py:233-244) with float32 and H2 terms / outputs gives the same values (the power-of-two scaling of
+    the H2 format commutes with every rounding of the sum)."""
+    from romp_amd.net import RompNet
+    from romp_amd.plan import encode_h2, decode_h2
+    from romp_amd import lib as L
+    import ctypes as C
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    B, Hh, Cc = 2, 32, 64
+    t0 = torch.randn(B, Hh, Hh, Cc, generator=g)
+    t1 = torch.randn(B, Hh // 2, Hh // 2, Cc, generator=g)
+    t2 = torch.randn(B, Hh // 4, Hh // 4, Cc, generator=g)
+    up = lambda t, f: t.repeat_interleave(f, 1).repeat_interleave(f, 2)
+    ref = torch.relu(t0 + up(t1, 2) + up(t2, 4))
+    # run through a two-op program: the fuse sum is reachable through the network executor only
+    from romp_amd.plan import Program, Act
+    from romp_amd.lib import RompOp, OP_FUSESUM, BUF_NONE
+    for fmts, ofmt in (((0, 0, 0), 0), ((1, 1, 1), 1), ((1, 0, 1), 0), ((0, 1, 0), 1)):
+        op = RompOp()
+        op.kind, op.in_buf, op.res_buf, op.out_buf = OP_FUSESUM, BUF_NONE, BUF_NONE, 3
+        op.H, op.W, op.Cin, op.Cout, op.relu, op.n_terms = Hh, Hh, Cc, Cc, 1, 3
+        op.out_cstride, op.out_fmt, op.act_shift = Cc, ofmt, 4
+        for k in range(3):
+            op.term_buf[k], op.term_shift[k], op.term_cstride[k], op.term_fmt[k] = k, k, Cc, fmts[k]
+        sizes = [Hh * Hh * Cc, Hh * Hh * Cc // 4, Hh * Hh * Cc // 16, Hh * Hh * Cc]
+        h = C.c_void_p()
+        arr = (RompOp * 1)(op)
+        L.check(lib.romp_net_create(C.byref(h), arr, 1, (C.c_int64 * 4)(*sizes), 4, B))
+        try:
+            for k, t in enumerate((t0, t1, t2)):
+                td = (encode_h2(t) if fmts[k] else t).to(dev).contiguous()
+                L.check(lib.romp_net_write_buffer(h, k, L.ptr(td), td.numel(), L.stream_ptr(dev)))
+            dummy = torch.zeros(B * 16, device=dev)
+            L.check(lib.romp_net_forward(h, L.ptr(dummy), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+            out = torch.empty(B * sizes[3], device=dev)
+            L.check(lib.romp_net_read_buffer(h, 3, B, L.ptr(out), out.numel(), L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            o = out.cpu().reshape(B, Hh, Hh, Cc)
+            if ofmt:
+                o = decode_h2(o)
+            err = (o - ref).abs().max().item()
+            print('fusesum term fmts', fmts, 'out fmt', ofmt, 'max-abs err %.3e' % err)
+            assert err < 2e-6
+        finally:
+            lib.romp_net_destroy(h)
 
 
 # ------------------------------------------------------------------------------ network
@@ -362,7 +428,7 @@ def test_net_benchmark_batch_vs_oracle(dev, B, conv_math):
     import romp_amd
     settings = romp_amd.romp_settings([])
     settings.GPU, settings.center_thresh, settings.max_batch, settings.conv_math = 0, 1.3, B, conv_math
-    sd = O.make_romp_state_dict(0)
+    sd = O.make_romp_state_dict(0, center_bias=2.0)         # bench.py's weights (romp_amd.synthetic default): ~12 persons / image
     smpl_model = O.make_synthetic_smpl(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
     model.model.autotune(B, iters=1)
