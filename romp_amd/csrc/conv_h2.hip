@@ -21,6 +21,8 @@ static ConvVariant kVariantsH2[] = {
     ROMP_CONV_VARIANT_H2(1, 1, 2, 2, 32, 32), ROMP_CONV_VARIANT_H2(1, 1, 2, 1, 32, 32), ROMP_CONV_VARIANT_H2(1, 1, 1, 2, 16, 32),
     ROMP_CONV_VARIANT_H2(1, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_H2(13, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_H2(13, 1, 2, 2, 32, 16),
     ROMP_CONV_VARIANT_H2(2, 1, 1, 2, 16, 16), ROMP_CONV_VARIANT_H2(2, 1, 2, 2, 16, 16), ROMP_CONV_VARIANT_H2(1, 1, 1, 2, 32, 32),
+    ROMP_CONV_VARIANT_H2(1, 1, 1, 1, 16, 32), ROMP_CONV_VARIANT_H2(1, 1, 1, 1, 32, 32), ROMP_CONV_VARIANT_H2(1, 1, 2, 1, 16, 32),
+    ROMP_CONV_VARIANT_H2(1, 1, 1, 1, 16, 16), ROMP_CONV_VARIANT_H2(2, 1, 1, 1, 16, 16), ROMP_CONV_VARIANT_H2(1, 2, 1, 1, 16, 32),
     ROMP_CONV_VARIANT_H2(1, 1, 4, 2, 32, 32), ROMP_CONV_VARIANT_H2(1, 1, 4, 1, 32, 32), ROMP_CONV_VARIANT_H2(1, 2, 1, 2, 16, 32),
 };
 ConvVariant* conv_variants_h2(int* n) { *n = (int)(sizeof(kVariantsH2) / sizeof(kVariantsH2[0])); return kVariantsH2; }

@@ -231,3 +231,48 @@ def test_resnet50_plan_inventory():
     assert sorted((o.pad_h, o.pad_w) for _, o in dec[:4]) == [(0, 0), (0, 1), (1, 0), (1, 1)]
     assert all(o.pad_h == -1 and o.pad_w == -1 for n, o in zip(P.names, P.ops) if o.kind == 2 and not n.startswith('deconv'))
     assert P.coord_off == 64 and P.head_in_ch == 72
+
+
+@pytest.mark.parametrize('model', ['romp', 'bev', 'resnet50'])
+def test_every_conv_has_a_kernel_for_its_formats(model):
+    """Lower each network with conv_math='f16x2' on the CPU: every tensor gets a format (float32 or the pre-split H2), producer and
+    consumers agree on it, and every conv op still has at least one kernel variant able to run it (an H2 input can only be read by
+    the f16x2 kernels)."""
+    from romp_amd import lib as L, synthetic as S
+    h = L.load()
+    if model == 'romp':
+        from romp_amd.plan import build_romp_hrnet32 as build
+        sd = S.make_romp_state_dict(0)
+    elif model == 'bev':
+        from romp_amd.bev_plan import build_bev_hrnet32 as build
+        sd = S.make_bev_state_dict(0)
+    else:
+        from romp_amd.resnet_plan import build_romp_resnet50 as build
+        sd = S.make_resnet_state_dict(0)
+    P = build(sd, 'cpu', 512, bf16x3='f16x2')
+    P.op_array()
+    buf = C.create_string_buffer(128)
+    written = {}
+    n_h2 = 0
+    for name, op in zip(P.names, P.ops):
+        if op.kind == L.OP_CONV:
+            for b, f in ((op.in_buf, op.in_fmt), (op.res_buf, op.res_fmt)):
+                if b >= 0 and b in written:
+                    assert written[b] == f, '%s reads buffer %d as format %d, it was written as %d' % (name, b, f, written[b])
+            valid = [v for v in range(h.romp_conv_num_variants()) if h.romp_conv_describe(C.byref(op), 32, v, buf, 128) == 0]
+            assert valid, 'no kernel variant for %s (k%d s%d Cin %d Cout %d, in fmt %d)' % (name, op.ksize, op.stride, op.Cin, op.Cout, op.in_fmt)
+            n_h2 += op.in_fmt == L.FMT_H2
+            if op.out_buf >= 0:
+                written[op.out_buf] = op.out_fmt
+        elif op.kind == L.OP_FUSESUM:
+            for k in range(op.n_terms):
+                assert written.get(op.term_buf[k], op.term_fmt[k]) == op.term_fmt[k], name
+            written[op.out_buf] = op.out_fmt
+        elif op.kind == L.OP_STEM:
+            written[op.out_buf] = op.out_fmt
+        elif op.kind not in (L.OP_FORK, L.OP_JOIN):
+            for b in (op.in_buf, op.res_buf):
+                assert b < 0 or written.get(b, L.FMT_F32) == L.FMT_F32, '%s (kind %d) would read an H2 tensor' % (name, op.kind)
+            if op.out_buf >= 0:
+                written[op.out_buf] = L.FMT_F32
+    assert n_h2 > 50, n_h2
