@@ -68,6 +68,10 @@ __device__ __forceinline__ float4 h2_unpack(uint2 hi, uint2 lo, float inv_act_sc
                        ((float)h[2] + (float)l[2]) * inv_act_scale, ((float)h[3] + (float)l[3]) * inv_act_scale);
 }
 
+constexpr int EPI_ROW = 144;                         // epilogue staging: bytes per pixel row: 32 floats + 16 (conflict-free 16-byte columns)
+constexpr int EPI_WAVE = 32 * EPI_ROW;               // per-wave staging tile
+constexpr int EPI_BYTES = 4 * EPI_WAVE;
+
 template <int KS, int S, int MT, int NT, int TW, int CK>
 struct ConvCfg {
     // KS = 1: 1x1, 2: 2x2 (one output parity of a ConvTranspose2d k4 s2), 3: 3x3, 13: 1x3 (Conv1d k=3 along W; rows of
@@ -86,7 +90,8 @@ struct ConvCfg {
     static constexpr int B_VEC = TAPS * QC * NW;
     static constexpr int NA = (A_VEC + 255) / 256;
     static constexpr int NB = (B_VEC + 255) / 256;
-    static constexpr int LDS_BYTES = (HR * HC * PS + TAPS * CK * NW + 4 * NW) * 4 + 16;
+    static constexpr int LDS_MAIN = (HR * HC * PS + TAPS * CK * NW + 4 * NW) * 4 + 16;      // pixels, weights, scale/shift slots, mailbox
+    static constexpr int LDS_BYTES = LDS_MAIN + EPI_BYTES;                                   // + the epilogue's staging tiles
 };
 
 struct Item { int b, ty, tx, n0, g; };
@@ -118,94 +123,110 @@ __device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, i
     return it;
 }
 
-// Epilogue of one work item: y = acc*scale + shift (+ residual) (ReLU), NHWC float4 stores.
-// Lane owns pixel li of pixel-block m and channels n0 + n*32 + 8*g4 + 4*lh + {0..3}.
-// All residual loads of the item are issued up front in ONE batch under ONE uniform branch (a
-// branch per float4 serialises MT*NT*4 dependent global round trips -- that alone held the
-// 3x3 kernels at ~100 TFLOP/s), ReLU is branch-free (max with 0 or -inf).
+// Epilogue of one work item: y = acc*scale + shift (+ residual) (ReLU).
+// The MFMA leaves a lane with pixel li of pixel-block m and channels n0 + n*32 + 8*g4 + 4*lh + {0..3}: stored from there, one
+// store instruction covers 32 bytes of each of 32 pixels.  Instead every 32-pixel x 32-channel block goes through a per-wave LDS
+// staging tile (32 rows of 128 + 16 bytes) and comes back TRANSPOSED: lane L owns channel octet L & 3 of pixels (L >> 2) and
+// (L >> 2) + 16, i.e. 32 contiguous bytes of a pixel, four lanes cover the block's whole 128-byte pixel row.  Residual loads and
+// output stores are then 16-byte accesses, 128 contiguous bytes per pixel -- in the float32 format and in H2 alike (an octet's
+// high and low units are the 32 bytes its floats would be).  All residual loads of the item are issued up front in one batch
+// under one uniform branch; ReLU is branch-free (max with 0 or -inf).
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][NT],
-                                              const float* sSc, int wave, int li, int lh) {
+                                              const float* sSc, char* sE, int wave, int li, int lh) {
     using C = ConvCfg<KS, S, MT, NT, TW, CK>;
     float* out = p.out + (size_t)cur.b * p.out_bs + p.out_co + cur.g * p.out_gs;
     const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
     const float floor_v = p.relu ? 0.f : -__builtin_inff();
-    unsigned pixo[MT], outo[MT];                     // residual pixel index; output offset (row / pixel strides may be sparse)
-    bool rowok[MT];                                  // partial tiles along H (e.g. Conv1d over B < TH sequences)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int mb = wave * MT + m;
-        const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
-        rowok[m] = oy < p.Ho;
-        pixo[m] = rowok[m] ? (unsigned)(oy * p.Wo + ox) : 0u;
-        outo[m] = rowok[m] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
-    }
     if (p.vec_io) {
-        float4 r[MT][NT][4];
-        if (res && p.res_h2) {
-            // H2 residual: this lane's 4 channels are half an octet: 8 bytes of the high unit and 8 of the low unit
-            uint2 rh[MT][NT][4], rl[MT][NT][4];
+        const int lane = lh * 32 + li;
+        const int oc = lane & 3;                      // channel octet of the 32-channel block this lane stores
+        unsigned pixo[MT][2], outo[MT][2];            // residual pixel index; output offset (row / pixel strides may be sparse)
+        bool rowok[MT][2];                            // partial tiles along H (e.g. Conv1d over B < TH sequences)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pp = (lane >> 2) + 16 * j, mb = wave * MT + m;
+                const int oy = cur.ty * C::TH + mb * C::RPB + pp / TW, ox = cur.tx * TW + pp % TW;
+                rowok[m][j] = oy < p.Ho;
+                pixo[m][j] = rowok[m][j] ? (unsigned)(oy * p.Wo + ox) : 0u;
+                outo[m][j] = rowok[m][j] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
+            }
+        float4 ra[MT][NT][2], rb[MT][NT][2];          // residual: channels 8*oc .. +3 / +4 .. +7 (float32), or high / low unit (H2)
+        if (res) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const char* rp = reinterpret_cast<const char*>(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8))) + lh * 8;
-                        rh[m][n][g4] = *reinterpret_cast<const uint2*>(rp);
-                        rl[m][n][g4] = *reinterpret_cast<const uint2*>(rp + 16);
+                    for (int j = 0; j < 2; ++j) {     // masked rows read pixel 0 (valid memory)
+                        const float* rp = res + (pixo[m][j] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + oc * 8));
+                        ra[m][n][j] = ldg4(rp);
+                        rb[m][n][j] = ldg4(rp + 4);
                     }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) r[m][n][g4] = h2_unpack(rh[m][n][g4], rl[m][n][g4], p.inv_act_scale);
-        } else if (res) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        r[m][n][g4] = ldg4(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + g4 * 8 + lh * 4)));   // masked rows read pixel 0 (valid memory)
-        } else {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) r[m][n][g4] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int cl = n * 32 + g4 * 8 + lh * 4;
-                const float4 sc = *reinterpret_cast<const float4*>(sSc + cl);
-                const float4 sh = *reinterpret_cast<const float4*>(sSc + C::NW + cl);
+            for (int n = 0; n < NT; ++n) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cl = n * 32 + g4 * 8 + lh * 4;
+                    const float4 sc = *reinterpret_cast<const float4*>(sSc + cl);
+                    const float4 sh = *reinterpret_cast<const float4*>(sSc + C::NW + cl);
                     float4 v;
-                    v.x = fmaxf(fmaf(acc[m][n][g4 * 4 + 0], sc.x, sh.x) + r[m][n][g4].x, floor_v);
-                    v.y = fmaxf(fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y) + r[m][n][g4].y, floor_v);
-                    v.z = fmaxf(fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z) + r[m][n][g4].z, floor_v);
-                    v.w = fmaxf(fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w) + r[m][n][g4].w, floor_v);
-                    if (p.out_h2) {
-                        uint2 hi, lo;
-                        h2_pack(v, p.act_scale, hi, lo);
-                        char* op_ = reinterpret_cast<char*>(out + (outo[m] + (unsigned)(cur.n0 + n * 32 + g4 * 8))) + lh * 8;
-                        if (rowok[m]) {
-                            *reinterpret_cast<uint2*>(op_) = hi;
-                            *reinterpret_cast<uint2*>(op_ + 16) = lo;
+                    v.x = fmaf(acc[m][n][g4 * 4 + 0], sc.x, sh.x);
+                    v.y = fmaf(acc[m][n][g4 * 4 + 1], sc.y, sh.y);
+                    v.z = fmaf(acc[m][n][g4 * 4 + 2], sc.z, sh.z);
+                    v.w = fmaf(acc[m][n][g4 * 4 + 3], sc.w, sh.w);
+                    *reinterpret_cast<float4*>(sE + li * EPI_ROW + (g4 * 8 + lh * 4) * 4) = v;
+                }
+                __builtin_amdgcn_wave_barrier();      // same wave: the DS unit executes its writes and reads in order
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pp = (lane >> 2) + 16 * j;
+                    float4 va = *reinterpret_cast<const float4*>(sE + pp * EPI_ROW + oc * 32);
+                    float4 vb = *reinterpret_cast<const float4*>(sE + pp * EPI_ROW + oc * 32 + 16);
+                    if (res) {
+                        float4 qa = ra[m][n][j], qb = rb[m][n][j];
+                        if (p.res_h2) {
+                            const uint4 hi = __builtin_bit_cast(uint4, qa), lo = __builtin_bit_cast(uint4, qb);
+                            qa = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), p.inv_act_scale);
+                            qb = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), p.inv_act_scale);
                         }
-                    } else if (rowok[m]) {
-                        *reinterpret_cast<float4*>(out + (outo[m] + (unsigned)(cur.n0 + cl))) = v;
+                        va.x += qa.x; va.y += qa.y; va.z += qa.z; va.w += qa.w;
+                        vb.x += qb.x; vb.y += qb.y; vb.z += qb.z; vb.w += qb.w;
+                    }
+                    va.x = fmaxf(va.x, floor_v); va.y = fmaxf(va.y, floor_v); va.z = fmaxf(va.z, floor_v); va.w = fmaxf(va.w, floor_v);
+                    vb.x = fmaxf(vb.x, floor_v); vb.y = fmaxf(vb.y, floor_v); vb.z = fmaxf(vb.z, floor_v); vb.w = fmaxf(vb.w, floor_v);
+                    float* op_ = out + (outo[m][j] + (unsigned)(cur.n0 + n * 32 + oc * 8));
+                    if (p.out_h2) {
+                        uint2 ha, la, hb, lb;
+                        h2_pack(va, p.act_scale, ha, la);
+                        h2_pack(vb, p.act_scale, hb, lb);
+                        va = __builtin_bit_cast(float4, make_uint4(ha.x, ha.y, hb.x, hb.y));      // high unit
+                        vb = __builtin_bit_cast(float4, make_uint4(la.x, la.y, lb.x, lb.y));      // low unit
+                    }
+                    if (rowok[m][j]) {
+                        *reinterpret_cast<float4*>(op_) = va;
+                        *reinterpret_cast<float4*>(op_ + 4) = vb;
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
     } else {
         // scalar path: output convs of the head (Cout = 142 / 1 / 3 into unaligned NHWC slots)
+        unsigned pixo[MT], outo[MT];
+        bool rowok[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int mb = wave * MT + m;
+            const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
+            rowok[m] = oy < p.Ho;
+            pixo[m] = rowok[m] ? (unsigned)(oy * p.Wo + ox) : 0u;
+            outo[m] = rowok[m] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll

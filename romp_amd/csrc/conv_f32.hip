@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    char* sE = reinterpret_cast<char*>(sA) + C::LDS_MAIN + wave * EPI_WAVE;      // this wave's epilogue staging tile
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         if (!(p.dbg & 16)) __syncthreads();   // every wave finished reading this stage
         if (pf && !(p.dbg & 2)) write_lds(last, slot ^ 1);
         if (last) {
-            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
     int* sQ_other = reinterpret_cast<int*>(smem + (grp ^ 1) * GROUP_FLOATS + C::HR * C::HC * C::PS + C::TAPS * CK * C::NW + 4 * C::NW);
 
     const int lane = tid & 63, wave = tid >> 6;
+    char* sE = reinterpret_cast<char*>(sA) + C::LDS_MAIN + wave * EPI_WAVE;      // this wave's epilogue staging tile
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(ConvParams p) {
                 // ---------------- memory phase: staging registers -> LDS, epilogue of a finished item
                 if (pf) write_lds(last, slot ^ 1);
                 if (last) {
-                    conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+                    conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -123,11 +123,13 @@ struct SplitCfg {
     // register-staged weight slab (whole chunk): [tap][piece][k16][kg][NW] 16-byte units
     static constexpr int B_UNITS = C::TAPS * NP * K16 * 2 * C::NW;
     static constexpr int NB = (B_UNITS + 255) / 256;
-    static constexpr int LDS_BYTES = A_BYTES + B_UNITS * 16 + 4 * C::NW * 4 + 16;
+    static constexpr int LDS_MAIN = A_BYTES + B_UNITS * 16 + 4 * C::NW * 4 + 16;
+    static constexpr int LDS_BYTES = LDS_MAIN + EPI_BYTES;
     // LDS-DMA weight rows: [dx][piece][k16][kg][NW] units of one tap row, double-buffered
     static constexpr int SUB_UNITS = C::KW * NP * K16 * 2 * C::NW;
     static constexpr int NBD = (SUB_UNITS + 255) / 256;
-    static constexpr int LDS_BYTES_DMA = A_BYTES + 2 * SUB_UNITS * 16 + 4 * C::NW * 4 + 32;
+    static constexpr int LDS_MAIN_DMA = A_BYTES + 2 * SUB_UNITS * 16 + 4 * C::NW * 4 + 32;
+    static constexpr int LDS_BYTES_DMA = LDS_MAIN_DMA + EPI_BYTES;
 };
 
 // LDS layout of a pixel's chunk.  bf16x3: [piece][CK channels].  f16x2: the H2 order, [octet][piece][8 channels], so that a
@@ -212,6 +214,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    char* sE = sA + X::LDS_MAIN + wave * EPI_WAVE;     // this wave's epilogue staging tile
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
@@ -340,7 +343,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
         if (pf && !(p.dbg & 2)) write_lds(last, slot ^ 1);
         ROMP_TRACE(13);                                // next stage written to LDS
         if (last) {
-            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
             ROMP_TRACE(14);                            // epilogue issued
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -395,6 +398,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    char* sE = sA + X::LDS_MAIN_DMA + wave * EPI_WAVE;            // this wave's epilogue staging tile
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
@@ -552,7 +556,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
             if (pfA && !(p.dbg & 2)) write_A(last_ch, slot ^ 1);
             ROMP_TRACE(13);
             if (last_ch) {
-                if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, wave, li, lh);
+                if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
                 ROMP_TRACE(14);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
