@@ -16,10 +16,10 @@ __global__ __launch_bounds__(256, 2) void conv_bxd_kernel(ConvParams p) {
 
 #define ROMP_CONV_VARIANT_BXD(KS, S, MT, NT, TW, CK)                                  \
     { KS, S, MT, NT, TW, CK, conv_bxd_kernel<KS, S, MT, NT, TW, CK>,                  \
-      SplitCfg<3, KS, S, MT, NT, TW, CK>::LDS_BYTES_DMA, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 2 }
+      SplitCfg<3, KS, S, MT, NT, TW, CK>::LDS_BYTES_DMA, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 2, 0 }
 #define ROMP_CONV_VARIANT_BX3(KS, S, MT, NT, TW, CK)                                  \
     { KS, S, MT, NT, TW, CK, conv_bx3_kernel<KS, S, MT, NT, TW, CK>,                  \
-      SplitCfg<3, KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 1 }
+      SplitCfg<3, KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 1, 0 }
 static ConvVariant kVariantsBx3[] = {
     ROMP_CONV_VARIANT_BX3(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_BX3(3, 1, 2, 1, 16, 16),
     ROMP_CONV_VARIANT_BX3(3, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_BX3(3, 1, 2, 2, 16, 16),

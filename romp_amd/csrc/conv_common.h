@@ -14,6 +14,7 @@ struct ConvParams {
     const uint4* w3;          // bf16x3-split weights (conv_bx3 / conv_bxd kernels), or nullptr
     const uint4* wh;          // f16x2-split weights (conv_h2 / conv_h2d kernels), or nullptr
     const float* scale_h;     // their epilogue scale (scale / (weight scale * act_scale))
+    const float* zero;        // >= 16 bytes of zeros in device memory (what out-of-image lanes of an LDS-DMA fetch)
     float act_scale;          // 2^act_shift, applied to the activations before the fp16 split
     float inv_act_scale;      // 2^-act_shift
     int in_h2, out_h2, res_h2;   // tensor formats: 0 = NHWC float32, 1 = H2 (pre-split fp16 pieces, see h2_pack below)
@@ -72,15 +73,15 @@ constexpr int EPI_ROW = 144;                         // epilogue staging: bytes 
 constexpr int EPI_WAVE = 32 * EPI_ROW;               // per-wave staging tile
 constexpr int EPI_BYTES = 4 * EPI_WAVE;
 
-template <int KS, int S, int MT, int NT, int TW, int CK>
-struct ConvCfg {
+template <int KS, int S, int MT, int NT, int TW, int CK, int NWV = 4>
+struct ConvCfg {                                     // NWV: waves per workgroup (each owns MT pixel blocks x NT channel blocks)
     // KS = 1: 1x1, 2: 2x2 (one output parity of a ConvTranspose2d k4 s2), 3: 3x3, 13: 1x3 (Conv1d k=3 along W; rows of
     // the "image" are independent sequences).  The zero padding before the first tap is a run-time parameter.
     static constexpr int KH = (KS == 13) ? 1 : KS;
     static constexpr int KW = (KS == 13) ? 3 : KS;
     static constexpr int TAPS = KH * KW;
     static constexpr int RPB = 32 / TW;              // tile rows per 32-pixel block
-    static constexpr int TH = 4 * MT * RPB;          // output tile rows
+    static constexpr int TH = NWV * MT * RPB;        // output tile rows
     static constexpr int HR = (TH - 1) * S + KH;     // haloed input rows
     static constexpr int HC = (TW - 1) * S + KW;
     static constexpr int PS = CK + 4;                // LDS floats per pixel (padded)
@@ -97,12 +98,13 @@ struct ConvCfg {
 struct Item { int b, ty, tx, n0, g; };
 
 constexpr int TRACE_SLOTS = 64, TRACE_WAVES = 4096;
-// one stamp per wave (lane 0): word 0 of the wave's slot block counts the stamps, words 1.. hold them
+// one stamp per wave (lane 0): word 0 of the wave's slot block counts the stamps, words 1.. hold them.  The kernel defines
+// `int tr_n = 0` and `constexpr int tr_wpw` = its waves per workgroup.
 #define ROMP_TRACE(code)                                                                             \
     do {                                                                                             \
         if (p.trace) {                                                                               \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();                              \
-            const unsigned w_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                 \
+            const unsigned w_ = blockIdx.x * (unsigned)tr_wpw + (threadIdx.x >> 6);                  \
             if ((threadIdx.x & 63) == 0 && w_ < (unsigned)TRACE_WAVES && tr_n < TRACE_SLOTS - 1) {   \
                 p.trace[(size_t)w_ * TRACE_SLOTS + 1 + tr_n] = (t_ << 8) | (unsigned)(code);         \
                 p.trace[(size_t)w_ * TRACE_SLOTS] = (unsigned long long)(tr_n + 1);                  \
@@ -131,10 +133,35 @@ __device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, i
 // output stores are then 16-byte accesses, 128 contiguous bytes per pixel -- in the float32 format and in H2 alike (an octet's
 // high and low units are the 32 bytes its floats would be).  All residual loads of the item are issued up front in one batch
 // under one uniform branch; ReLU is branch-free (max with 0 or -inf).
-template <int KS, int S, int MT, int NT, int TW, int CK>
+template <int MT, int NT>
+struct EpiRes { float4 ra[MT][NT][2], rb[MT][NT][2]; };   // residual values of an item in the transposed (store) ownership
+
+// Issue the residual loads of an item early (e.g. before its last MFMA block): the epilogue then finds them in registers.
+template <int KS, int S, int MT, int NT, int TW, int CK, int NWV = 4>
+__device__ __forceinline__ void conv_epilogue_prefetch(const ConvParams& p, const Item& cur, int wave, int lane, EpiRes<MT, NT>& pre) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK, NWV>;
+    const float* res = p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs;
+    const int oc = lane & 3;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = (lane >> 2) + 16 * j, mb = wave * MT + m;
+            const int oy = cur.ty * C::TH + mb * C::RPB + pp / TW, ox = cur.tx * TW + pp % TW;
+            const unsigned pixo = oy < p.Ho ? (unsigned)(oy * p.Wo + ox) : 0u;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float* rp = res + (pixo * (unsigned)p.res_cs + (unsigned)(cur.n0 + n * 32 + oc * 8));
+                pre.ra[m][n][j] = ldg4(rp);
+                pre.rb[m][n][j] = ldg4(rp + 4);
+            }
+        }
+}
+
+template <int KS, int S, int MT, int NT, int TW, int CK, int NWV = 4>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][NT],
-                                              const float* sSc, char* sE, int wave, int li, int lh) {
-    using C = ConvCfg<KS, S, MT, NT, TW, CK>;
+                                              const float* sSc, char* sE, int wave, int li, int lh, const EpiRes<MT, NT>& pre, bool use_pre) {
+    using C = ConvCfg<KS, S, MT, NT, TW, CK, NWV>;
     float* out = p.out + (size_t)cur.b * p.out_bs + p.out_co + cur.g * p.out_gs;
     const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
     const float floor_v = p.relu ? 0.f : -__builtin_inff();
@@ -154,7 +181,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                 outo[m][j] = rowok[m][j] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
             }
         float4 ra[MT][NT][2], rb[MT][NT][2];          // residual: channels 8*oc .. +3 / +4 .. +7 (float32), or high / low unit (H2)
-        if (res) {
+        if (res && use_pre) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { ra[m][n][j] = pre.ra[m][n][j]; rb[m][n][j] = pre.rb[m][n][j]; }
+        } else if (res) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -247,14 +281,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
     }
 }
 
+// without prefetched residuals
+template <int KS, int S, int MT, int NT, int TW, int CK, int NWV = 4>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][NT],
+                                              const float* sSc, char* sE, int wave, int li, int lh) {
+    EpiRes<MT, NT> none;
+    conv_epilogue<KS, S, MT, NT, TW, CK, NWV>(p, cur, acc, sSc, sE, wave, li, lh, none, false);
+}
+
 typedef void (*conv_fn)(ConvParams);
-// math: 0 f32 MFMA, 1 bf16x3 (register-staged weights), 2 bf16x3 (LDS-DMA weight rows), 3 / 4 the same two for f16x2
-struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; };
+// math: 0 f32 MFMA, 1 bf16x3 (register-staged weights), 2 bf16x3 (LDS-DMA weight rows), 3 / 4 the same two for f16x2,
+// 5 f16x2 fully LDS-DMA-fed pipeline (conv_h2p.hip), 6 the same with the layer's weights resident in LDS.  threads: workgroup size (0 = 256, or 512 for the ping-pong kernels).
+struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; int threads; };
 
 // per translation unit: its table of instantiated kernels
 ConvVariant* conv_variants_f32(int* n);
 ConvVariant* conv_variants_bx3(int* n);
 ConvVariant* conv_variants_h2(int* n);
 ConvVariant* conv_variants_h2d(int* n);
+ConvVariant* conv_variants_h2p(int* n);
 
 }  // namespace romp

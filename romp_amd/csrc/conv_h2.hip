@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvParams p) {
 
 #define ROMP_CONV_VARIANT_H2(KS, S, MT, NT, TW, CK)                                   \
     { KS, S, MT, NT, TW, CK, conv_h2_kernel<KS, S, MT, NT, TW, CK>,                   \
-      SplitCfg<2, KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 3 }
+      SplitCfg<2, KS, S, MT, NT, TW, CK>::LDS_BYTES, ConvCfg<KS, S, MT, NT, TW, CK>::TH, 0, 0, 3, 0 }
 static ConvVariant kVariantsH2[] = {
     ROMP_CONV_VARIANT_H2(3, 1, 2, 1, 32, 16), ROMP_CONV_VARIANT_H2(3, 1, 2, 1, 16, 16),
     ROMP_CONV_VARIANT_H2(3, 1, 2, 2, 32, 16), ROMP_CONV_VARIANT_H2(3, 1, 2, 2, 16, 16),

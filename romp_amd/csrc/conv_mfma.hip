@@ -46,11 +46,13 @@ static void collect_variants() {
     t = conv_variants_bx3(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2d(&n); kVariants.insert(kVariants.end(), t, t + n);
+    t = conv_variants_h2p(&n); kVariants.insert(kVariants.end(), t, t + n);
     kNumVariants = (int)kVariants.size();
 }
 static bool g_attr_done = false;
 static int g_num_cu = 256;
 static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers without an arena
+static float* g_zero = nullptr;             // 256 bytes of zeros (out-of-image lanes of LDS-DMA pixel fetches)
 static unsigned long long* g_trace = nullptr;   // env ROMP_CONV_TRACE=1: per-wave phase stamps of the most recent split-precision conv launch
 
 static const int kMaxLds = 160 * 1024;
@@ -70,10 +72,12 @@ static int ensure_attrs() {
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kVariants[i].lds));
         int occ = 0;
         ROMP_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kVariants[i].fn),
-                                                                    kVariants[i].pp ? 512 : 256, kVariants[i].lds));
+                                                                    kVariants[i].threads ? kVariants[i].threads : (kVariants[i].pp ? 512 : 256), kVariants[i].lds));
         kVariants[i].occ = occ > 0 ? occ : 1;
     }
     ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, QUEUE_INTS * sizeof(int)));
+    ROMP_HIP_CHECK(hipMalloc((void**)&g_zero, 256));
+    ROMP_HIP_CHECK(hipMemset(g_zero, 0, 256));
     { const char* e = getenv("ROMP_CONV_TRACE");
       if (e && atoi(e)) ROMP_HIP_CHECK(hipMalloc((void**)&g_trace, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long))); }
     g_attr_done = true;
@@ -88,7 +92,9 @@ static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) 
     if (v.lds > kMaxLds) return false;
     if ((v.math == 1 || v.math == 2) && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.math >= 3 && (op.weight_h2 == nullptr || op.scale_h2 == nullptr || (op.cin_pad & 15))) return false;
-    if (op.in_fmt == ROMP_FMT_H2 && v.math < 3) return false;          // only the f16x2 kernels stage pre-split activations
+    if (op.in_fmt == ROMP_FMT_H2 && v.math < 3) return false;
+    if (v.math >= 5 && (op.in_fmt != ROMP_FMT_H2 || op.cin_pad < 32)) return false;   // the DMA pipeline copies pre-split pixels
+    if (v.math == 6 && (op.cin_pad != 32 || op.cout_pad != v.nt * 32 || op.groups != 1)) return false;   // resident weights: one slab for every item          // only the f16x2 kernels stage pre-split activations
     if ((op.out_fmt == ROMP_FMT_H2 || op.res_fmt == ROMP_FMT_H2) && !(op.Cout == op.cout_pad)) return false;   // vector epilogue only
     if (v.ks != op.ksize || v.s != op.stride) return false;
     if (Wo % v.tw) return false;                     // rows may be partial (masked), columns may not
@@ -132,6 +138,7 @@ bool conv_variant_valid(const romp_op& op, int variant) {
 
 int launch_conv(const romp_op& op, const float* in, const float* res, float* out, int B, int mode,
                 int variant, int* queue, hipStream_t st, int wg_cap) {
+    { const int rc = ensure_attrs(); if (rc) return rc; }         // one-time setup (zero page, scratch queue, LDS attributes)
     ROMP_REQUIRE(op.ksize == 1 || op.ksize == 2 || op.ksize == 3 || op.ksize == 13, "conv: ksize %d unsupported", op.ksize);
     ROMP_REQUIRE(op.stride == 1 || op.stride == 2, "conv: stride %d unsupported", op.stride);
     ROMP_REQUIRE(op.groups >= 1, "conv: groups must be >= 1");
@@ -142,6 +149,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.w3 = reinterpret_cast<const uint4*>(op.weight_aux);
     p.wh = reinterpret_cast<const uint4*>(op.weight_h2);
     p.scale_h = op.scale_h2;
+    p.zero = g_zero;
     p.act_scale = ldexpf(1.f, op.act_shift);
     p.inv_act_scale = ldexpf(1.f, -op.act_shift);
     p.in_h2 = op.in_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.res_h2 = res && op.res_fmt == ROMP_FMT_H2;
@@ -180,8 +188,6 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
         ROMP_HIP_CHECK(hipGetLastError());
         return ROMP_OK;
     }
-    int rc = ensure_attrs();
-    if (rc) return rc;
     if (variant < 0) variant = choose_variant(op, p.Ho, p.Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants && variant_ok(kVariants[variant], op, p.Ho, p.Wo),
                  "conv: no kernel variant (%d) for k%d s%d Cin %d(pad %d) Cout %d(pad %d) out %dx%d", variant,
@@ -208,7 +214,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
         p.trace = g_trace;
         ROMP_HIP_CHECK(hipMemsetAsync(g_trace, 0, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long), st));
     }
-    hipLaunchKernelGGL(v.fn, dim3((unsigned)grid), dim3(v.pp ? 512 : 256), v.lds, st, p);
+    hipLaunchKernelGGL(v.fn, dim3((unsigned)grid), dim3(v.threads ? v.threads : (v.pp ? 512 : 256)), v.lds, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }
@@ -228,7 +234,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 4 ? "conv_h2d" : v.math == 3 ? "conv_h2" : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 6 ? "conv_h2w" : v.math == 5 ? "conv_h2p" : v.math == 4 ? "conv_h2d" : v.math == 3 ? "conv_h2" : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }

@@ -23,6 +23,11 @@ def run_case(case, B, variants, dbg):
     P.conv('t', Act(0, cin, H, H, cin), [w], [torch.ones(cout)], [torch.zeros(cout)], k, s, True,
            res=Act(1, cout, Ho, Ho, cout) if use_res else None)
     op = P.ops[0]
+    if os.environ.get('ABLATE_FMT', 'h2') == 'h2':
+        from romp_amd.plan import encode_h2, ACT_SHIFT
+        op.in_fmt = op.out_fmt = 1
+        op.res_fmt = 1 if use_res else 0
+        op.act_shift = ACT_SHIFT
     out = torch.empty(B, Ho, Ho, cout, device=dev)
     buf = C.create_string_buffer(128)
     flops = 2.0 * B * Ho * Ho * cout * cin * k * k
@@ -55,7 +60,7 @@ if __name__ == '__main__':
     kind = os.environ.get('ABLATE_KIND', 'mfma')
     kinds = kind.split(',')
     vs = lambda *tags: [k + '_' + t for k in kinds for t in tags]
-    cases = [((64, 64, 3, 1, 64, True), vs('k3s1_mt2_nt2_tw16_ck16', 'k3s1_mt2_nt1_tw16', 'k3s1_mt1_nt2_tw16')),
+    cases = [((64, 64, 3, 1, 64, True), vs('k3s1_mt2_nt2_tw16_ck16', 'k3s1_mt2_nt1_tw16', 'k3s1_mt1_nt2_tw16', 'k3s1_mt1_nt2_tw32', 'k3s1_mt1_nt1_tw16')),
              ((32, 32, 3, 1, 128, True), vs('k3s1_mt2_nt1_tw16', 'k3s1_mt2_nt1_tw32', 'k3s1_mt4_nt1_tw32', 'k3s1_mt1_nt1_tw16')),
              ((128, 128, 3, 1, 32, True), vs('k3s1_mt2_nt2_tw16_ck16', 'k3s1_mt1_nt2_tw16'))]
     for case, variants in cases:

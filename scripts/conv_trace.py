@@ -34,6 +34,10 @@ def run(case, B, tags):
     P.conv('t', Act(0, cin, H, H, cin), [w], [torch.ones(cout)], [torch.zeros(cout)], k, s, True,
            res=Act(1, cout, Ho, Ho, cout) if use_res else None)
     op = P.ops[0]
+    from romp_amd.plan import ACT_SHIFT
+    op.in_fmt = op.out_fmt = 1                   # H2 tensors (timing only: the input bytes are whatever randn left there)
+    op.res_fmt = 1 if use_res else 0
+    op.act_shift = ACT_SHIFT
     out = torch.empty(B, Ho, Ho, cout, device=dev)
     buf = C.create_string_buffer(128)
     st = torch.cuda.current_stream().cuda_stream
