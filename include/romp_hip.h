@@ -235,10 +235,13 @@ int  romp_project_verts(const float* verts, int N, int V, const float* cam, cons
 /* ------------------------------------------------------------------ callers either side */
 
 /* img_preprocess (utils.py:16-30) on device: BGR uint8 (H,W,3) -> RGB float32 (S,S,3) 0..255, centred zero
- * pad to square + bicubic resize (OpenCV INTER_CUBIC convention, float arithmetic).  pad_info_host[6]
- * receives top,bottom,left,right,h,w. */
+ * pad to square + cv::resize(INTER_CUBIC) in OpenCV's fixed-point arithmetic (11-bit coefficients, replicated
+ * border, saturate).  pad_info_host[6] receives top,bottom,left,right,h,w. */
 int  romp_preprocess(const unsigned char* bgr_u8, int H, int W, float* out_rgb_f32, int out_size,
                      float* pad_info_host, void* stream);
+/* The same for B frames of one size, (B,H,W,3) -> (B,S,S,3), in one launch (video / batch mode). */
+int  romp_preprocess_batch(const unsigned char* bgr_u8, int B, int H, int W, float* out_rgb_f32, int out_size,
+                           float* pad_info_host, void* stream);
 /* BEV per-image post-processing (bev/post_parser.py:68-136,167-222): camera translation, perspective
  * projection (normalised and original-image pixels), projection-based duplicate suppression, outlier
  * removal.  Persons of image b are rows offsets[b]..offsets[b+1]-1 (offsets: B+1 int32, device);

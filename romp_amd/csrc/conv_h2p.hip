@@ -62,6 +62,16 @@ __device__ __forceinline__ void wait_all_and_barrier() {    // raw barrier: this
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
+// The same, but the N youngest VMEM operations (the epilogue's output stores, issued after the DMA pieces) may stay in flight:
+// memory operations retire in order, so everything older -- the DMA -- has landed.
+template <int N>
+__device__ __forceinline__ void wait_but_and_barrier() {
+    static_assert(N == 4 || N == 8 || N == 16, "store count of an epilogue");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 struct StageDesc {              // wave-uniform description of one stage's sources
     const float* in;            // image + group + chunk base of the pixel tensor
@@ -211,6 +221,9 @@ __global__ __launch_bounds__(512, 2) void conv_h2p_kernel(ConvParams p) {
     bool have_next = j_next < p.per_queue;
     if (have_next) nxt = decode_item(p, q, j_next, C::NW);
     int ch = 0, buf = 0, slot = 0;
+    EpiRes<MT, NT> pre;
+    const bool use_pre = p.res && p.vec_io;
+    const bool full_tiles = p.Ho % C::TH == 0 && p.vec_io;              // every output store of an epilogue is issued: its count is known
     wait_all_and_barrier();
     ROMP_TRACE(4);
 
@@ -220,9 +233,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2p_kernel(ConvParams p) {
         const bool has_nx = (!last || have_next) && !(p.dbg & 1);       // is there a next stage to fetch?
         const StageDesc nd = make_desc(last ? nxt : cur, last ? 0 : (ch + 1) * CK);
         const int nslot = last ? slot ^ 1 : slot;
-        EpiRes<MT, NT> pre;
-        const bool use_pre = last && p.res && p.vec_io;
-        if (use_pre) conv_epilogue_prefetch<3, 1, MT, NT, TW, CK, NWV>(p, cur, wave, lane, pre);
+        if (ch == 0 && use_pre) conv_epilogue_prefetch<3, 1, MT, NT, TW, CK, NWV>(p, cur, wave, lane, pre);   // an item ahead of its use
         ROMP_TRACE(10);
         {
             const char* sA = sBuf + buf * X::STAGE_BYTES;
@@ -278,7 +289,9 @@ __global__ __launch_bounds__(512, 2) void conv_h2p_kernel(ConvParams p) {
             ++ch;
         }
         buf ^= 1;
-        wait_all_and_barrier();             // the next stage has landed; everybody is done with the buffer the stage after it overwrites
+        // the next stage has landed; everybody is done with the buffer the stage after it overwrites.  Right after an epilogue the
+        // item's output stores stay in flight (they drain under the next item's first MFMA blocks).
+        if (last && full_tiles) wait_but_and_barrier<MT * NT * 4>(); else wait_all_and_barrier();
         ROMP_TRACE(12);
     }
 }

@@ -88,6 +88,16 @@ static int ensure_attrs() {
 // that it never runs inside a stream capture (hipMalloc / hipFuncSetAttribute are illegal there).
 int conv_init() { return ensure_attrs(); }
 
+// The LDS-DMA pipeline kernels (conv_h2p.hip) take a whole CU per workgroup.  Measured alone they beat the two-per-CU f16x2
+// kernels by 5-10 % on the 64- and 128-channel layers, but inside the network the kernels of the other branch streams can no
+// longer share their CUs and the batch-32 forward got 11 % SLOWER (2 066 vs 2 327 images/s), so the autotuner only sees them
+// when ROMP_CONV_PIPE=1.  Explicit variant indices (tests, scripts/conv_ablate.py) always work.
+static int g_pipe_auto = -1;
+static bool pipe_in_autotune() {
+    if (g_pipe_auto < 0) { const char* e = getenv("ROMP_CONV_PIPE"); g_pipe_auto = (e && atoi(e)) ? 1 : 0; }
+    return g_pipe_auto == 1;
+}
+
 static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) {
     if (v.lds > kMaxLds) return false;
     if ((v.math == 1 || v.math == 2) && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
@@ -128,6 +138,11 @@ static void out_dims(const romp_op& op, int* Ho, int* Wo) {
 }
 
 int conv_num_variants() { collect_variants(); return kNumVariants; }
+
+bool conv_variant_valid(const romp_op& op, int variant);
+bool conv_variant_tunable(const romp_op& op, int variant) {
+    return conv_variant_valid(op, variant) && (kVariants[variant].math < 5 || pipe_in_autotune());
+}
 
 bool conv_variant_valid(const romp_op& op, int variant) {
     collect_variants();

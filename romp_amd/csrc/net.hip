@@ -413,7 +413,7 @@ int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
         if (op.kind != ROMP_OP_CONV) continue;
         float best_ms = 1e30f;
         for (int v = 0; v < conv_num_variants(); ++v) {
-            if (!conv_variant_valid(op, v)) continue;
+            if (!conv_variant_tunable(op, v)) continue;
             float ms_min = 1e30f;
             for (int it = 0; it < iters + 1 && rc == ROMP_OK; ++it) {
                 rc = reset_queues(n, st);

@@ -1,11 +1,12 @@
 // post.hip -- the callers either side of the network (SURVEY.md §8f "next" rows 1 and 2):
 //
 //  * preprocess_kernel: img_preprocess (simple_romp/romp/utils.py:16-30) on device -- BGR->RGB,
-//    centred zero pad to a square, bicubic resize to 512x512 (OpenCV INTER_CUBIC convention: pixel
-//    centres, a = -0.75, replicated border), round + saturate to uint8, -> float32 (1,512,512,3).
-//    The caller uploads the uint8 frame (0.25 B/px/ch) instead of the float tensor (4x the bytes).
-//    OpenCV's fixed-point rounding is not reproduced (cv2 is a third-party dependency that is not
-//    available to pin against): parity is against the float restatement in romp_amd/utils.py.
+//    centred zero pad to a square, cv::resize(INTER_CUBIC) to 512x512 in OpenCV's own arithmetic (pixel
+//    centres, a = -0.75, 11-bit fixed-point coefficients, int32 horizontal pass, (v + 2^21) >> 22,
+//    saturate, replicated border) -> float32 (B,512,512,3).  The caller uploads uint8 frames (0.25 B/px/ch)
+//    instead of the float tensor (4x the bytes).  Bit-exact against the test suite's CPU
+//    restatement of OpenCV's published scalar algorithm (cv2 itself is not installed here; its SIMD
+//    builds round the vertical pass in float32, which can differ by one grey level on rare pixels).
 //
 //  * bev_post_kernel: BEV's per-image post-processing (simple_romp/bev/post_parser.py):
 //    denormalize_cam_params_to_trans :114-128, perspective_projection :68-107 (+ to-original-image
@@ -16,38 +17,55 @@
 
 namespace romp {
 
-__device__ __forceinline__ void cubic_coeffs(float fx, float* c) {
-    const float A = -0.75f;
-    c[0] = ((A * (fx + 1.f) - 5.f * A) * (fx + 1.f) + 8.f * A) * (fx + 1.f) - 4.f * A;
-    c[1] = ((A + 2.f) * fx - (A + 3.f)) * fx * fx + 1.f;
-    c[2] = ((A + 2.f) * (1.f - fx) - (A + 3.f)) * (1.f - fx) * (1.f - fx) + 1.f;
-    c[3] = 1.f - c[0] - c[1] - c[2];
+// cv::resize(INTER_CUBIC) tables for one destination coordinate, exactly as OpenCV builds them (resize.cpp: the sampling
+// position in double, the cubic weights in float with A = -0.75, then 11-bit fixed point with round-half-even).  The
+// explicit __f*_rn / __d*_rn keep hipcc from contracting a*b+c into an FMA, which OpenCV's scalar code does not do.
+__device__ __forceinline__ void cv_cubic_tab(int d, int src, int dst, int& s0, int (&coef)[4]) {
+    const double scale = 1.0 / ((double)dst / (double)src);
+    const float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    const int fl = (int)floorf(f);
+    const float x = __fsub_rn(f, (float)fl);
+    const float xp = __fadd_rn(x, 1.f), xm = __fsub_rn(1.f, x);
+    float c[4];
+    c[0] = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(-0.75f, xp), -3.75f), xp), -6.f), xp), -3.f);
+    c[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(1.25f, x), 2.25f), x), x), 1.f);
+    c[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(1.25f, xm), 2.25f), xm), xm), 1.f);
+    c[3] = __fsub_rn(__fsub_rn(__fsub_rn(1.f, c[0]), c[1]), c[2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) coef[k] = min(max((int)rintf(__fmul_rn(c[k], 2048.f)), -32768), 32767);
+    s0 = fl - 1;
 }
 
-__global__ void preprocess_kernel(const unsigned char* __restrict__ src, int H, int W, int side, int top, int left,
-                                  float* __restrict__ dst, int S) {
+// One thread per output pixel of one frame (blockIdx.y): the 4x4 taps of the PADDED square image (zero padding around the
+// frame, replicated border of the padded image), horizontal pass to int32, vertical pass, (v + 2^21) >> 22, saturate.
+__global__ void preprocess_kernel(const unsigned char* __restrict__ src_all, int H, int W, int side, int top, int left,
+                                  float* __restrict__ dst_all, int S) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * S) return;
+    const unsigned char* src = src_all + (size_t)blockIdx.y * H * W * 3;
+    float* dst = dst_all + (size_t)blockIdx.y * S * S * 3;
     const int ox = i % S, oy = i / S;
-    const float scale = (float)side / (float)S;
-    const float fy = (oy + 0.5f) * scale - 0.5f, fx = (ox + 0.5f) * scale - 0.5f;
-    const int sy = (int)floorf(fy), sx = (int)floorf(fx);
-    float cy[4], cx[4];
-    cubic_coeffs(fy - sy, cy);
-    cubic_coeffs(fx - sx, cx);
-    float acc[3] = {0.f, 0.f, 0.f};
+    int sx, sy, ca[4], cb[4];
+    cv_cubic_tab(ox, side, S, sx, ca);
+    cv_cubic_tab(oy, side, S, sy, cb);
+    int acc[3] = {0, 0, 0};
+#pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int py = min(max(sy - 1 + a, 0), side - 1) - top;          // replicated border of the PADDED image
+        const int py = min(max(sy + a, 0), side - 1) - top;             // replicated border of the PADDED image
+        int row[3] = {0, 0, 0};
+#pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int px = min(max(sx - 1 + b, 0), side - 1) - left;
+            const int px = min(max(sx + b, 0), side - 1) - left;
             // branch-free (taps in the zero padding read pixel 0 with weight 0): all 48 byte loads of a thread in flight
             const bool ok = (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
             const unsigned char* p = src + (ok ? ((size_t)py * W + px) * 3 : 0);
-            const float wgt = ok ? cy[a] * cx[b] : 0.f;
-            acc[0] += wgt * p[2]; acc[1] += wgt * p[1]; acc[2] += wgt * p[0];       // BGR -> RGB
+            const int wgt = ok ? ca[b] : 0;
+            row[0] += wgt * (int)p[2]; row[1] += wgt * (int)p[1]; row[2] += wgt * (int)p[0];       // BGR -> RGB
         }
+        acc[0] += row[0] * cb[a]; acc[1] += row[1] * cb[a]; acc[2] += row[2] * cb[a];
     }
-    for (int c = 0; c < 3; ++c) dst[(size_t)i * 3 + c] = fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(size_t)i * 3 + c] = (float)min(max((acc[c] + (1 << 21)) >> 22, 0), 255);
 }
 
 constexpr int PJ = 71, PMAX = 64;
@@ -154,7 +172,23 @@ int romp_preprocess(const unsigned char* bgr_u8, int H, int W, float* out_rgb_f3
         pad_info_host[3] = (float)(left + W); pad_info_host[4] = (float)H; pad_info_host[5] = (float)W;
     }
     const int total = out_size * out_size;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, bgr_u8, H, W, side, top,
+    hipLaunchKernelGGL(preprocess_kernel, dim3((total + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, bgr_u8, H, W, side, top,
+                       left, out_rgb_f32, out_size);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+int romp_preprocess_batch(const unsigned char* bgr_u8, int B, int H, int W, float* out_rgb_f32, int out_size, float* pad_info_host,
+                          void* stream) {
+    ROMP_REQUIRE(bgr_u8 && out_rgb_f32 && B > 0 && B < 65536 && H > 0 && W > 0 && out_size > 0, "romp_preprocess_batch: bad arguments");
+    const int side = H > W ? H : W;
+    const int top = (side - H) / 2, left = (side - W) / 2;
+    if (pad_info_host) {
+        pad_info_host[0] = (float)top; pad_info_host[1] = (float)(top + H); pad_info_host[2] = (float)left;
+        pad_info_host[3] = (float)(left + W); pad_info_host[4] = (float)H; pad_info_host[5] = (float)W;
+    }
+    const int total = out_size * out_size;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((total + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, bgr_u8, H, W, side, top,
                        left, out_rgb_f32, out_size);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;

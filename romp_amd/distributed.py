@@ -52,7 +52,7 @@ def all_gather_records(local, width, device, group=None):
     n_local = 0 if local is None else local.shape[0]
     counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=device), group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = torch.cat(counts).tolist()                                 # one host sync for all ranks' counts
     n_max = max(counts)
     if n_max == 0:
         return torch.zeros(0, width, device=device), counts
@@ -87,11 +87,27 @@ def unpack_records(rec, with_joints=False, with_verts=False):
     return out
 
 
-def sharded_forward(model, images_local, img_offset, with_joints=True, with_verts=False, group=None):
-    """Run `model.forward_batch` (romp_amd.ROMP) on this rank's shard and all-gather the records.
-    Returns (dict of gathered tensors, per-rank counts)."""
-    outputs, batch_ids = model.forward_batch(images_local)
+def local_records(model, images_local, img_offset, chunk=None, with_joints=True, with_verts=False):
+    """net -> parse -> SMPL over this rank's shard, walked in chunks of `chunk` images (the batch size the context was
+    built and tuned for; None: one call), as one (N, R) record matrix with GLOBAL image ids (shard offset + position in the
+    shard: the rule of the reference's training tree, romp/lib/maps_utils/result_parser.py:280-282), or None."""
+    n = images_local.shape[0]
+    chunk = n if not chunk else int(chunk)
+    recs = []
+    for c0 in range(0, n, chunk):
+        outputs, batch_ids = model.forward_batch(images_local[c0:c0 + chunk])
+        r = pack_records(outputs, batch_ids, img_offset + c0, with_joints=with_joints, with_verts=with_verts)
+        if r is not None:
+            recs.append(r)
+    if not recs:
+        return None
+    return recs[0] if len(recs) == 1 else torch.cat(recs, 0)
+
+
+def sharded_forward(model, images_local, img_offset, with_joints=True, with_verts=False, group=None, chunk=None):
+    """Run `model.forward_batch` (romp_amd.ROMP) on this rank's shard (in chunks of `chunk` images) and all-gather the
+    records ONCE.  Returns (dict of gathered tensors, per-rank counts)."""
     dev = images_local.device
-    rec = pack_records(outputs, batch_ids, img_offset, with_joints=with_joints, with_verts=with_verts)
+    rec = local_records(model, images_local, img_offset, chunk, with_joints, with_verts)
     allrec, counts = all_gather_records(rec, record_width(with_joints, with_verts), dev, group)
     return unpack_records(allrec, with_joints, with_verts), counts

@@ -94,6 +94,7 @@ def load():
         'smpl_forward': (C.c_int, [vp, vp, i32, vp, i32, i32, vp, vp, vp]),
         'smpl_ctx_destroy': (None, [vp]),
         'romp_preprocess': (C.c_int, [vp, i32, i32, vp, i32, C.POINTER(C.c_float), vp]),
+        'romp_preprocess_batch': (C.c_int, [vp, i32, i32, i32, vp, i32, C.POINTER(C.c_float), vp]),
         'romp_bev_postprocess': (C.c_int, [vp, vp, vp, i32, vp, f, f, vp, vp, vp, vp, vp]),
         'romp_project': (C.c_int, [vp, i32, i32, vp, C.POINTER(C.c_float), vp, vp, vp, vp]),
     }
@@ -112,7 +113,7 @@ EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_f
            'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_trace_read', 'romp_conv_describe',
            'romp_net_autotune', 'romp_net_tuned_variant', 'romp_net_set_tuned', 'romp_net_set_split', 'romp_project_verts', 'romp_oneeuro_state_floats', 'romp_oneeuro_smooth', 'romp_sim3dr_normals', 'romp_sim3dr_light', 'romp_sim3dr_rasterize', 'romp_bev_workspace_ints', 'romp_bev_parse', 'romp_bev_regress',
            'romp_net_buffer_ptr', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
-           'romp_project', 'romp_preprocess', 'romp_bev_postprocess']
+           'romp_project', 'romp_preprocess', 'romp_preprocess_batch', 'romp_bev_postprocess']
 
 
 def check(rc):

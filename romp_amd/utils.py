@@ -20,34 +20,34 @@ def padding_image(image):
     return pad_image, torch.Tensor([top, bottom, left, right, h, w])
 
 
-def _cubic_coeffs(fx, A=-0.75):
-    """OpenCV INTER_CUBIC kernel (a = -0.75) for fractional offset fx in [0,1)."""
-    c = np.empty(fx.shape + (4,), np.float64)
-    c[..., 0] = ((A * (fx + 1) - 5 * A) * (fx + 1) + 8 * A) * (fx + 1) - 4 * A
-    c[..., 1] = ((A + 2) * fx - (A + 3)) * fx * fx + 1
-    c[..., 2] = ((A + 2) * (1 - fx) - (A + 3)) * (1 - fx) * (1 - fx) + 1
-    c[..., 3] = 1. - c[..., 0] - c[..., 1] - c[..., 2]
-    return c
+def _cv_cubic_table(src, dst):
+    """cv::resize INTER_CUBIC tables (OpenCV resize.cpp): per destination coordinate the first tap index and the four weights
+    in 11-bit fixed point -- position in double, weights in float32 (A = -0.75), saturate_cast<short>(w * 2048)."""
+    f32 = np.float32
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * (1.0 / (float(dst) / float(src))) - 0.5).astype(f32)
+    s = np.floor(f).astype(np.int64)
+    x = f - s.astype(f32)
+    A, xp, xm = f32(-0.75), x + f32(1), f32(1) - x
+    c0 = ((A * xp - f32(5) * A) * xp + f32(8) * A) * xp - f32(4) * A
+    c1 = ((A + f32(2)) * x - (A + f32(3))) * x * x + f32(1)
+    c2 = ((A + f32(2)) * xm - (A + f32(3))) * xm * xm + f32(1)
+    c3 = f32(1) - c0 - c1 - c2
+    w = np.rint(np.stack([c0, c1, c2, c3], 1).astype(f32) * f32(2048)).astype(np.int64)
+    return s - 1, np.clip(w, -32768, 32767)
 
 
 def resize_bicubic_u8(img, size):
-    """Separable bicubic resize with OpenCV's sampling convention (pixel centres, a=-0.75,
-    replicated border); float arithmetic, rounded/saturated to uint8.  Used only when cv2 is
-    not installed (OpenCV's fixed-point rounding is not reproduced: pre-processing parity is
-    unpinned)."""
-    src = img.astype(np.float64)
-    for axis in (0, 1):
-        n_in = src.shape[axis]
-        scale = n_in / float(size)
-        f = (np.arange(size) + 0.5) * scale - 0.5
-        s0 = np.floor(f).astype(np.int64)
-        c = _cubic_coeffs(f - s0)
-        idx = np.clip(s0[:, None] + np.arange(-1, 3)[None], 0, n_in - 1)
-        g = np.take(src, idx, axis=axis)              # axis -> (size, 4)
-        shape = [1] * g.ndim
-        shape[axis], shape[axis + 1] = size, 4
-        src = (g * c.reshape(shape)).sum(axis=axis + 1)
-    return np.clip(np.rint(src), 0, 255).astype(np.uint8)
+    """cv2.resize(img, (size, size), interpolation=cv2.INTER_CUBIC) for uint8 images without OpenCV: the library's scalar
+    fixed-point algorithm (replicated border, int32 horizontal pass, (v + 2^21) >> 22, saturate) -- the arithmetic the device
+    kernel (csrc/post.hip) uses too.  OpenCV's SIMD builds round the vertical pass in float32 and may differ by one grey level
+    on rare pixels (pre-processing parity with a real cv2 stays unpinned: the module is not installed here)."""
+    h, w = img.shape[:2]
+    xs, xa = _cv_cubic_table(w, size)
+    ys, yb = _cv_cubic_table(h, size)
+    src = img.astype(np.int64)
+    hp = (src[:, np.clip(xs[:, None] + np.arange(4), 0, w - 1)] * xa[None, :, :, None]).sum(2)
+    vp = (hp[np.clip(ys[:, None] + np.arange(4), 0, h - 1)] * yb[:, :, None, None]).sum(1)
+    return np.clip((vp + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
 
 
 def img_preprocess(image, input_size=512):

@@ -197,6 +197,24 @@ def test_img_preprocess_contract():
     assert y[0, 256, 256].tolist() == [0.0, 0.0, 200.0]
 
 
+def test_host_preprocess_fallback_matches_oracle():
+    """Without cv2 the host pre-processing path runs OpenCV's fixed-point INTER_CUBIC restated in numpy: identical to the oracle
+    (and so to the device kernel, which tests/test_bev_post.py holds to the same oracle)."""
+    from oracle import cv_resize_oracle as CV
+    from romp_amd.utils import img_preprocess
+    rs = np.random.RandomState(3)
+    for shp in ((90, 160), (240, 135), (64, 64), (700, 333)):
+        img = rs.randint(0, 256, shp + (3,)).astype(np.uint8)
+        a, pa = CV.img_preprocess(img)
+        b, pb = img_preprocess(img)
+        assert np.array_equal(a, b.numpy()) and pa.tolist() == pb.tolist()
+    # the 11-bit tables: weights of a whole-pixel position are (0, 2048, 0, 0); every row sums to 2048 +- 1
+    s0, w = CV.cubic_tables(64, 64)
+    assert np.array_equal(w, np.tile([0, 2048, 0, 0], (64, 1))) and np.array_equal(s0, np.arange(64) - 1)
+    _, w2 = CV.cubic_tables(1920, 512)
+    assert np.abs(w2.sum(1) - 2048).max() <= 1
+
+
 def test_translation_lsq_recovers_known_translation():
     from romp_amd.post_parser import estimate_translation_lsq
     rs = np.random.RandomState(1)

@@ -91,3 +91,54 @@ def test_allgather_records_nobody_anywhere():
     res = _run([0, 0])
     for rank, got, image_ids, s, jshape in res:
         assert got == [0, 0] and image_ids == [] and jshape == (0, 71, 3)
+
+
+class _StubModel:
+    """forward_batch of a fake ROMP: image b (whose pixel [0,0,0] holds its global id v) yields v % 3 persons whose thetas are
+    all v -- enough to check ids / order / chunking without a GPU."""
+
+    def forward_batch(self, images):
+        ids = images[:, 0, 0, 0].long()
+        bids = torch.cat([torch.full((int(v) % 3,), b, dtype=torch.int64) for b, v in enumerate(ids.tolist())] or [torch.zeros(0, dtype=torch.int64)])
+        n = bids.numel()
+        if n == 0:
+            return None, None
+        v = ids[bids].float()
+        out = {'cam': v.view(n, 1).repeat(1, 3), 'smpl_thetas': v.view(n, 1).repeat(1, 72), 'smpl_betas': torch.zeros(n, 10),
+               'center_confs': torch.ones(n, 1), 'center_preds': torch.zeros(n, 2, dtype=torch.int64), 'joints': torch.zeros(n, 71, 3)}
+        return out, bids
+
+
+def _chunk_worker(rank, world, port, n_images, chunk, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from romp_amd import distributed as D
+    lo, hi = D.shard_range(n_images, rank, world)
+    images = torch.zeros(hi - lo, 2, 2, 3)
+    images[:, 0, 0, 0] = torch.arange(lo, hi).float()
+    out, counts = D.sharded_forward(_StubModel(), images, lo, with_joints=True, chunk=chunk)
+    q.put((rank, counts, out['image_ids'].tolist(), out['smpl_thetas'][:, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_forward_chunked_global_ids():
+    """The north-star job shape in miniature: a global batch sharded contiguously over 2 ranks, each shard walked in chunks
+    (also a ragged last chunk), ONE all-gather per step: every rank ends with all persons in global image order, ids global."""
+    n_images, world = 11, 2
+    for chunk in (2, 3, None):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_chunk_worker, args=(r, world, port, n_images, chunk, q)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res = [q.get(timeout=120) for _ in ps]
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        want = [v for v in range(n_images) for _ in range(v % 3)]
+        for rank, counts, ids, th in res:
+            assert ids == want and th == [float(v) for v in want]
+            assert sum(counts) == len(want)
