@@ -4,17 +4,21 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the hot path over one batch of synthetic images PER GPU
-(BASELINE.json configs[1]: ROMP HRNet-32, 512x512, batch 32):  network (323 fused layer
-kernels) -> center-map parse -> SMPL meshes for every detection -> (N>1: RCCL all-gather of the
-per-person records over xGMI).  Inputs are resident in HBM when the timed region starts.
-Weights are seeded synthetic tensors of the reference's shapes (the licensed ROMP.pkl /
-SMPL_NEUTRAL.pth cannot be shipped); arithmetic is float32 end to end.
+Default workload (BASELINE.json): a synthetic job of `--global-batch` = 1024 pre-processed 512x512 images, sharded
+contiguously over the N GPUs (BASELINE configs[2]); every rank walks its shard in forward calls of `--batch` = 32 images
+(BASELINE configs[1], the batch the headline metric is quoted on): network (323 fused layer kernels, one hipGraph replay)
+-> center-map parse -> SMPL meshes for every detection, then ONE RCCL all-gather of the per-person records of the whole
+step over xGMI (N > 1).  A "step" is one pass over the whole job, so N = 1 times exactly the batch-32 hot path (32 calls
+per step) and the per-N values form a STRONG-scaling curve.  `--global-batch 0` gives the weak-scaling mode of round 1
+(`--batch` images per GPU per step).  Inputs are resident in HBM when the timed region starts.  Weights are seeded
+synthetic tensors of the reference's shapes (the licensed ROMP.pkl / SMPL_NEUTRAL.pth cannot be shipped); arithmetic is
+float32-accurate end to end (convs as f16x2-split products with f32 accumulation; `mesh_max_abs_vs_oracle` reports it).
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).  After the timed
-region rank 0 additionally measures (a) the per-kernel-class roofline with HIP events on the
-launch stream and (b) the CPU baseline (the oracle restatement of the reference, timed on the
-host cores of this box on a bounded sample of the same workload).
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).  After the timed region rank 0 additionally
+measures (a) the per-kernel-class roofline with HIP events on the launch stream, (b) parity of the timed batch against the
+oracle (maps, detections, meshes), (c) the same job end to end from uint8 host frames (H2D + device pre-processing inside the
+timed region) and (d) the CPU baseline (the oracle restatement of the reference, timed on the host cores of this box on a
+bounded sample of the same workload).
 """
 import argparse
 import ctypes as C
@@ -30,10 +34,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf16,f16} dense peak
 BX3_PRODUCTS = 6                  # bf16 piece products issued per f32 product by the bf16x3 kernels
 H2_PRODUCTS = 3                   # fp16 piece products issued per f32 product by the f16x2 kernels
 PEAK_HBM_GBS = 8000.0
+PROFILE_TAG = 'r02'               # profiles/<tag>_pmc_*_by_kernel.csv: the committed rocprofv3 PMC passes of this build
 
 
 def parse_args():
@@ -41,10 +46,12 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='images per forward call (BASELINE configs[1]: 32)')
+    ap.add_argument('--global-batch', type=int, default=1024,
+                    help='images per step over ALL GPUs, sharded contiguously (BASELINE configs[2]: 1024); 0: weak scaling, --batch images per GPU per step')
     ap.add_argument('--center-thresh', type=float, default=1.3)
     ap.add_argument('--workload', type=str, default='romp', choices=['romp', 'bev', 'smpl'],
-                    help="romp = BASELINE configs[1] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A); smpl = configs[4] (SMPL-only, 64 persons)")
+                    help="romp = BASELINE configs[1]/[2] (default, the headline metric); bev = configs[3] (BEV head, 3-D parse, SMPL-A); smpl = configs[4] (SMPL-only, 64 persons)")
     ap.add_argument('--graph', type=int, default=1, help='replay the network from a hipGraph')
     ap.add_argument('--conv-math', type=str, default='f16x2', choices=['f32', 'bf16x3', 'f16x2', 'all'],
                     help='f32: exact f32 MFMA kernels only; f16x2 / bf16x3 / all: also offer the f32-accurate split-precision kernels '
@@ -53,24 +60,58 @@ def parse_args():
     ap.add_argument('--autotune', type=int, default=1, help='pick conv kernel variants by measurement at start-up')
     ap.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
                     help='resnet50: BASELINE configs[0]\'s model (the reference runs it on the CPU only) at the headline batch size')
-    ap.add_argument('--split', type=int, default=1, help='2: run the batch as two half-batch lanes on two streams (convs capped at --wg-cap WG/CU)')
-    ap.add_argument('--wg-cap', type=int, default=1)
     ap.add_argument('--tune-file', type=str, default=None,
                     help='JSON cache of the autotuned variant table: loaded if it exists (no measuring launches), else written')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle comparison of the timed batch')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the uint8-host-frames (H2D + pre-processing) timing')
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the extra conv_math=f32 timing of the same workload')
     ap.add_argument('--with-verts', type=int, default=0, help='N>1: also all-gather the 6890x3 vertices')
     return ap.parse_args()
 
 
-def roofline_report(model, images, lib, L):
-    """Per kernel variant: sum of algorithmic FLOPs / bytes over its launches / sum of HIP-event
-    durations (events recorded on the launch stream around every layer kernel)."""
-    net = model.model
-    if net.split == 2:                       # batch lanes: the kernels run on half batches
-        images = images[:images.shape[0] // 2].contiguous()
+# ------------------------------------------------------------------------------------------------ roofline
+def kernel_of(variant_name):
+    import re
+    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2|h2d|h2p|h2w|h2q)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    if not m:
+        return None
+    fam, ks, s, mt, nt, tw, ck = m.groups()
+    if fam == 'h2q':
+        return 'conv_h2q_kernel<%s, %s, %s>' % (mt, nt, tw)
+    if fam in ('h2p', 'h2w'):
+        return 'conv_h2p_kernel<%s, %s, %s, %s>' % (mt, nt, tw, 'true' if fam == 'h2w' else 'false')
+    return 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % (fam, ks, s, mt, nt, tw, ck)
+
+
+def pmc_traffic(variant_name, pmc_dir):
+    """HBM bytes per launch of the kernel behind `variant_name` from the committed rocprofv3 PMC passes
+    (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv, produced by scripts/gpu_profile.sh: separate --pmc passes of
+    this same command; unit KiB per dispatch; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).
+    None if the files or the kernel are missing -- PMC counters cannot be read from inside this process, and a stale
+    file (kernel no longer in the variant table) must not be quoted."""
+    import csv
+    kern = kernel_of(variant_name)
+    if kern is None:
+        return None
+    vals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        path = os.path.join(pmc_dir, '%s_pmc_%s_by_kernel.csv' % (PROFILE_TAG, counter))
+        if not os.path.exists(path):
+            return None
+        for row in csv.DictReader(open(path)):
+            if kern in row['kernel']:
+                vals[counter] = float(row[counter + '_mean']) * 1024.0
+    if len(vals) != 2:
+        return None
+    return dict(bytes=2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'], kernel=kern)
+
+
+def roofline_report(net, images):
+    """Per kernel variant: sum of algorithmic FLOPs / bytes over its launches / sum of HIP-event durations (events recorded
+    on the launch stream around every layer kernel, ops serialised on one stream)."""
     B = images.shape[0]
     ms = net.profile(images, iters=3)
     agg = {}
@@ -84,55 +125,36 @@ def roofline_report(model, images, lib, L):
         classes[k] = dict(launches=a['launches'], ms=round(a['ms'], 4),
                           tflops=round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 2) if a['ms'] > 0 else 0.0,
                           gbs=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1) if a['ms'] > 0 else 0.0)
-    dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
-    name, a = dom
+    name, a = max(agg.items(), key=lambda kv: kv[1]['ms'])
     achieved = a['flops'] / (a['ms'] * 1e-3) / 1e12
-    # `achieved` counts ALGORITHMIC flops (2*M*N*K of the f32 convolution).  A bf16x3 kernel issues six
-    # bf16 MFMA products per algorithmic product, so its roof is the bf16 dense peak / 6; the f32 kernels
-    # are priced against the f32 MFMA peak.
-    bx3 = 'conv_bx' in name                  # conv_bx3_* and conv_bxd_*: the bf16x3-split kernels
-    h2 = 'conv_h2' in name                   # conv_h2_* and conv_h2d_*: the f16x2-split kernels
+    # `achieved` counts ALGORITHMIC flops (2*M*N*K of the f32 convolution).  A split-precision kernel issues 6 (bf16x3) or
+    # 3 (f16x2) 16-bit MFMA products per algorithmic product, so its matrix roof is the 16-bit dense peak / products; the f32
+    # kernels are priced against the f32 MFMA peak.  The HBM view of the same kernel is reported beside it (hbm_frac): with
+    # three products the 3x3 layers sit near the ridge, and whichever fraction is larger is the binding roof.
+    bx3, h2 = 'conv_bx' in name, 'conv_h2' in name
     products = BX3_PRODUCTS if bx3 else H2_PRODUCTS if h2 else 1
     peak = PEAK_BF16_MFMA_TFLOPS / products if (bx3 or h2) else PEAK_F32_MFMA_TFLOPS
-    roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s',
-                frac=round(achieved / peak, 4), traffic=None,
+    hbm_gbs = a['bytes'] / (a['ms'] * 1e-3) / 1e9
+    mfma_frac, hbm_frac = achieved / peak, hbm_gbs / PEAK_HBM_GBS
+    roof = dict(bound='hbm' if hbm_frac > mfma_frac else 'mfma', kernel=name)
+    if roof['bound'] == 'hbm':
+        roof.update(achieved=round(hbm_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(hbm_frac, 4))
+    else:
+        roof.update(achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(mfma_frac, 4))
+    roof.update(traffic=None,
                 pipe=('%s MFMA 32x32x16, %d piece products per f32 product' % ('bf16' if bx3 else 'f16', products)) if (bx3 or h2) else 'f32 MFMA 32x32x2',
-                issued_tflops=round(achieved * products, 1),
-                frac_of_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                tflops=round(achieved, 2), mfma_peak_tflops=round(peak, 1), mfma_frac=round(mfma_frac, 4),
+                hbm_gbs=round(hbm_gbs, 1), hbm_frac=round(hbm_frac, 4),
+                issued_tflops=round(achieved * products, 1), frac_of_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 launches=a['launches'], avg_launch_ms=round(a['ms'] / a['launches'], 5),
                 flops_per_launch=a['flops'] / a['launches'], alg_bytes_per_launch=a['bytes'] / a['launches'],
-                hbm_gbs=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9, 1), hbm_frac=round(a['bytes'] / (a['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                net_ms_per_batch=round(sum(ms), 3))
+                net_ms_per_batch=round(sum(ms), 3), batch=B)
     t = pmc_traffic(name, os.path.join(ROOT, 'profiles'))
     if t is not None:                        # measured in a separate rocprofv3 --pmc pass of this command (profiles/README.md)
         roof['traffic'] = round(t['bytes'])
-        roof['traffic_source'] = 'profiles/r01_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % t['kernel']
+        roof['traffic_source'] = 'profiles/%s_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % (PROFILE_TAG, t['kernel'])
         roof['traffic_over_algorithmic'] = round(t['bytes'] / (a['bytes'] / a['launches']), 3)
     return roof, classes
-
-
-def pmc_traffic(variant_name, pmc_dir):
-    """HBM bytes per launch of the kernel behind `variant_name` from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv, produced by scripts/gpu_profile.sh: separate --pmc passes of
-    this same command; unit KiB per dispatch; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).
-    None if the files or the kernel are missing -- PMC counters cannot be read from inside this process."""
-    import csv
-    import re
-    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2|h2d)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
-    if not m:
-        return None
-    kern = 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % m.groups()
-    vals = {}
-    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
-        path = os.path.join(pmc_dir, 'r01_pmc_%s_by_kernel.csv' % counter)
-        if not os.path.exists(path):
-            return None
-        for row in csv.DictReader(open(path)):
-            if kern in row['kernel']:
-                vals[counter] = float(row[counter + '_mean']) * 1024.0
-    if len(vals) != 2:
-        return None
-    return dict(bytes=2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'], kernel=kern)
 
 
 def usable_cores():
@@ -162,6 +184,7 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline / parity
 def cpu_baseline(sd, smpl_model, thresh, seconds):
     """The oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
     from oracle import romp_oracle as O
@@ -187,10 +210,73 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
     if n == 0:
         n, dt = 1, warm
     return dict(value=round(Bc * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload, torch-CPU float32 '
-                       '(reference onnxruntime path unavailable: module not installed)' % (n, Bc))
+                sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload: the oracle restatement of the reference on '
+                       'torch-CPU float32 (kind=port: /root/reference does not exist on the GPU box, and its onnxruntime path needs a module that '
+                       'is not installed)' % (n, Bc))
 
 
+def parity_report(model, images, sd, smpl_model, thresh, pick=(0, 17)):
+    """Images `pick` of the timed batch: HIP maps / detections / meshes against the oracle pipeline (BASELINE metric:
+    'mesh max-abs-err vs ref')."""
+    import numpy as np
+    from oracle import romp_oracle as O
+    torch.set_num_threads(usable_cores())
+    pick = [p for p in pick if p < images.shape[0]]
+    cm, pm = model.model(images)
+    out, bids = model.forward_batch(images)
+    torch.cuda.synchronize()
+    cm_o, pm_o = O.romp_net_forward(sd, images[pick].cpu())
+    rep = {'images_compared': pick,
+           'maps_max_abs_vs_oracle': float(max((cm[pick].cpu() - cm_o).abs().max(), (pm[pick].cpu() - pm_o).abs().max()))}
+    ref = O.parsing_outputs(cm_o.numpy(), pm_o.numpy(), thresh)
+    if out is None or ref is None:
+        rep['detections_equal'] = (out is None or not any(int(b) in pick for b in bids.tolist())) and ref is None
+        return rep
+    b = bids.cpu().numpy()
+    rows = np.concatenate([np.nonzero(b == p)[0] for p in pick])
+    same = (len(rows) == len(ref['batch_ids']) and np.array_equal(np.searchsorted(pick, b[rows]), ref['batch_ids']) and
+            np.array_equal(out['center_preds'].cpu().numpy()[rows], ref['center_preds']))
+    rep['detections_equal'] = bool(same)
+    rep['persons_compared'] = int(len(rows))
+    if same and len(rows):
+        th, be = out['smpl_thetas'].cpu().numpy()[rows], out['smpl_betas'].cpu().numpy()[rows]
+        v = out['verts'].cpu().numpy()[rows]
+        vo, _, _ = O.smpl_forward(smpl_model, be, th)                                   # identical theta / beta (the 1e-4 gate)
+        vr, _, _ = O.smpl_forward(smpl_model, ref['smpl_betas'], ref['smpl_thetas'])    # the oracle's own theta / beta
+        rep['mesh_max_abs_vs_oracle'] = float(np.abs(v - vo).max())
+        rep['mesh_max_abs_end_to_end'] = float(np.abs(v - vr).max())
+        rep['thetas_max_abs_vs_oracle'] = float(np.abs(th - ref['smpl_thetas']).max())
+    return rep
+
+
+def end_to_end(model, lib, L, dev, batch, n_calls, stream):
+    """The same job starting from uint8 frames in (pinned) host memory: H2D of 0.79 MB/image + batched device pre-processing
+    (BGR->RGB, pad, cv::resize-exact INTER_CUBIC; csrc/post.hip) + net + parse + SMPL, all inside the timed region."""
+    g = torch.Generator().manual_seed(11)
+    frames = torch.randint(0, 256, (batch, 512, 512, 3), generator=g, dtype=torch.uint8).pin_memory()
+    fdev = torch.empty(batch, 512, 512, 3, device=dev, dtype=torch.uint8)
+    x = torch.empty(batch, 512, 512, 3, device=dev, dtype=torch.float32)
+    pad = (C.c_float * 6)()
+
+    def call():
+        fdev.copy_(frames, non_blocking=True)
+        L.check(lib.romp_preprocess_batch(L.ptr(fdev), batch, 512, 512, L.ptr(x), 512, pad, L.stream_ptr(dev)))
+        return model.forward_batch(x)
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n_calls):
+            call()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    return dict(value=round(batch * n_calls / dt, 2), unit='images/s', ms_per_call=round(dt / n_calls * 1e3, 3), calls=n_calls,
+                includes='per call: H2D of %d uint8 512x512x3 frames from pinned host memory + device pre-processing + net + parse + SMPL '
+                         '(one stream, no copy/compute overlap)' % batch)
+
+
+# ------------------------------------------------------------------------------------------------ other workloads
 def bench_smpl(args, dev):
     """BASELINE configs[4]: SMPL-only microbench, 64 persons x 6890 verts (blend shapes + LBS + 71 joints), HIP vs
     the torch-CPU oracle.  HBM-bound: per launch the kernels read betas/thetas, the blend-shape bases (v_template,
@@ -230,7 +316,7 @@ def bench_smpl(args, dev):
            'roofline': {'bound': 'hbm', 'achieved': round((base_bytes + out_bytes) / (gpu_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                         'frac': round((base_bytes + out_bytes) / (gpu_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), 'traffic': None,
                         'alg_bytes_per_launch': base_bytes + out_bytes, 'gflops_per_launch': round(flops / 1e9, 3),
-                        'note': 'five small kernels per launch (pose, skin, joints); launch latency bound at N=64'}}
+                        'note': 'the SMPL kernels of one call (pose, skin, joints); latency bound at N=64'}}
     if not args.no_cpu_baseline:
         from oracle import romp_oracle as O
         torch.set_num_threads(usable_cores())
@@ -252,22 +338,24 @@ def bench_bev(args, dev):
     s = bev.bev_settings([])
     s.GPU, s.max_batch, s.conv_math = dev.index or 0, args.batch, args.conv_math
     sd = S.make_bev_state_dict(0)
-    model = bev.BEV(s, state_dict=sd, smpla_model=S.make_smpl_model(0, 11), smil_model=S.make_smpl_model(5, 10))
+    smpla, smil = S.make_smpl_model(0, 11), S.make_smpl_model(5, 10)
+    model = bev.BEV(s, state_dict=sd, smpla_model=smpla, smil_model=smil)
     images = S.make_images(args.batch, seed=4, device=dev)
+    net = model.model.net
     if args.autotune:
-        model.model.net.autotune(args.batch)
+        net.autotune(args.batch)
     pads = torch.tensor([[0., 512., 0., 512., 512., 512.]]).repeat(args.batch, 1)
     # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
     # ~12 persons per image, the load the ROMP line runs at
-    lo, hi = 0.0, 8.0
+    t_lo, t_hi = 0.0, 8.0
     for _ in range(14):
-        mid = 0.5 * (lo + hi)
+        mid = 0.5 * (t_lo + t_hi)
         model.model.centermap_parser.conf_thresh = mid
         r = model.forward_batch(images)
         kept = 0 if r is None else r['cam'].shape[0] / args.batch
         if 10.0 <= kept <= 14.0:
             break
-        lo, hi = (mid, hi) if kept > 14.0 else (lo, mid)
+        t_lo, t_hi = (mid, t_hi) if kept > 14.0 else (t_lo, mid)
     n = 0
     for _ in range(args.warmup):
         r = model.forward_batch(images, pads)
@@ -278,18 +366,46 @@ def bench_bev(args, dev):
         n = 0 if r is None else r['cam'].shape[0]
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    ms = model.model.net.profile(images, iters=2)
-    print(json.dumps({'metric': 'images/sec (512x512, BEV HRNet-32)', 'value': round(args.batch * args.steps / dt, 2),
-                      'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-                      'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-                      'vs_baseline': None, 'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (%s-split conv products)' % args.conv_math, 'data': 'synthetic',
-                      'config': {'workload': 'BEV HRNet-32 + BEV head 512x512 batch=%d (BASELINE configs[3]); net+3D parse+'
-                                             'regression+SMPL-A+post-processing' % args.batch,
-                                 'persons_kept_per_image': round(n / args.batch, 2), 'net_ms_per_batch': round(sum(ms), 3),
-                                 'head_ms_per_batch': round(sum(t for t, nm in zip(ms, model.model.net.program.names) if nm.startswith('bev.')), 3)}}),
-          flush=True)
+    res = {'metric': 'images/sec (512x512, BEV HRNet-32)', 'value': round(args.batch * args.steps / dt, 2),
+           'unit': 'images/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+           'vs_baseline': None, 'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (%s-split conv products)' % args.conv_math, 'data': 'synthetic',
+           'config': {'workload': 'BEV HRNet-32 + BEV head 512x512 batch=%d (BASELINE configs[3]); net+3D parse+'
+                                  'regression+SMPL-A+post-processing' % args.batch,
+                      'persons_kept_per_image': round(n / args.batch, 2), 'center_thresh': round(mid, 4)}}
+    if not args.no_roofline:
+        s1 = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s1):
+            roof, classes = roofline_report(net, images)
+            ms = net.profile(images, iters=2)
+        head_ms = sum(t for t, nm in zip(ms, net.program.names) if nm.startswith('bev.'))
+        c3 = [(t, by) for t, nm, by in zip(ms, net.program.names, net.program.bytes) if 'refine' in nm]
+        roof['head_ms_per_batch'] = round(head_ms, 3)
+        if c3:
+            gbs = sum(by for _, by in c3) * args.batch / (sum(t for t, _ in c3) * 1e-3) / 1e9
+            roof['conv3d_refiners'] = {'launches': len(c3), 'ms': round(sum(t for t, _ in c3), 4), 'hbm_gbs': round(gbs, 1),
+                                       'hbm_frac': round(gbs / PEAK_HBM_GBS, 4)}
+        res['roofline'] = roof
+        res['kernel_classes'] = classes
+    if not args.no_cpu_baseline:
+        from oracle import bev_oracle as BO
+        torch.set_num_threads(usable_cores())
+        img1 = images[:1].cpu()
+        sd = dict(sd)
+        sd['coordmap_3d'] = BO.coordmap_3d()                     # the oracle's constant buffer (bev/model.py:9-17)
+        t0 = time.time()
+        BO.bev_forward(sd, img1, mid)
+        warm = time.time() - t0
+        t0, k = time.time(), 0
+        while warm < args.cpu_seconds / 2 and time.time() - t0 < args.cpu_seconds and k < 8:
+            BO.bev_forward(sd, img1, mid); k += 1
+        cdt = (time.time() - t0) if k else warm
+        res['cpu_baseline'] = dict(value=round(max(k, 1) / cdt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                                   sample='%d single-image BEV forwards (network + 3-D parse + regression) of the torch-CPU oracle restatement' % max(k, 1))
+    print(json.dumps(res), flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ headline
 def main():
     args = parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -309,57 +425,60 @@ def main():
         return bench_bev(args, dev)
     if args.workload == 'smpl':
         return bench_smpl(args, dev)
+    B = args.batch
     settings = romp_amd.romp_settings([])
-    settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, args.batch
+    settings.GPU, settings.center_thresh, settings.max_batch = local_rank, args.center_thresh, B
     settings.conv_math, settings.backbone = args.conv_math, args.backbone
     if args.backbone == 'resnet50':
         sd = S.make_resnet_state_dict(0, center_bias=2.0)
-        args.no_cpu_baseline = True                      # the cpu_baseline leg times the HRNet-32 oracle
+        args.no_cpu_baseline = args.no_parity = True          # those legs run the HRNet-32 oracle
     else:
         sd = S.make_romp_state_dict(0)
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
     model.model.set_streams(args.streams)
-    if args.split == 2:
-        model.model.set_split(2, args.wg_cap)
-    Bt = args.batch // 2 if args.split == 2 else args.batch          # batch the kernels see
     if args.tune_file and os.path.exists(args.tune_file):
-        model.model.set_tuned(Bt, json.load(open(args.tune_file))[str(Bt)])
+        model.model.set_tuned(B, json.load(open(args.tune_file))[str(B)])
     elif args.autotune:
-        model.model.autotune(Bt)
+        model.model.autotune(B)
         if args.tune_file and rank == 0:
-            json.dump({str(Bt): model.model.tuned_variants(Bt)}, open(args.tune_file, 'w'))
+            json.dump({str(B): model.model.tuned_variants(B)}, open(args.tune_file, 'w'))
     if args.graph:
         model.model.set_graph(True)
-    B = args.batch
-    lo, hi = D.shard_range(B * world, rank, world)            # weak scaling: B images per GPU
-    images = S.make_images(B, seed=1 + rank, device=dev)
+    strong = args.global_batch > 0
+    G = args.global_batch if strong else B * world
+    lo, hi = D.shard_range(G, rank, world)
+    n_local = hi - lo
+    # the shard, resident in HBM: seeded uint8 noise generated on the device chunk by chunk (1024 x 3.1 MB of float32)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    images = torch.empty(n_local, 512, 512, 3, device=dev, dtype=torch.float32)
+    for c0 in range(0, n_local, 64):
+        images[c0:c0 + 64] = torch.randint(0, 256, images[c0:c0 + 64].shape, device=dev, generator=gen, dtype=torch.uint8).float()
     stream = torch.cuda.Stream(dev)
-    persons = 0
     if args.backbone == 'resnet50':
         # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
         # ~12 persons per image, the load the HRNet-32 line runs at
-        lo, hi = -8.0, 16.0
+        t_lo, t_hi = -8.0, 16.0
         with torch.cuda.stream(stream):
             for _ in range(16):
-                mid = 0.5 * (lo + hi)
+                mid = 0.5 * (t_lo + t_hi)
                 model.centermap_parser.conf_thresh = mid
-                out, _ = model.forward_batch(images)
-                kept = 0 if out is None else out['cam'].shape[0] / B
+                out, _ = model.forward_batch(images[:B])
+                kept = 0 if out is None else out['cam'].shape[0] / min(B, n_local)
                 if 10.0 <= kept <= 14.0:
                     break
-                lo, hi = (mid, hi) if kept > 14.0 else (lo, mid)
+                t_lo, t_hi = (mid, t_hi) if kept > 14.0 else (t_lo, mid)
         args.center_thresh = round(mid, 4)
+    persons = 0
 
     def step():
         nonlocal persons
         if world > 1:
-            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts))
+            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts), chunk=B)
             persons = sum(counts)
         else:
-            out, bids = model.forward_batch(images)
-            persons = 0 if out is None else out['cam'].shape[0]
-        return out
+            rec = D.local_records(model, images, lo, chunk=B, with_joints=True, with_verts=bool(args.with_verts))
+            persons = 0 if rec is None else rec.shape[0]
 
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
@@ -380,28 +499,41 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_images = B * world * args.steps
+    bb = 'HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'
+    if strong:
+        workload = ('ROMP %s 512x512, batch=%d synthetic images sharded across %d GPU%s (BASELINE configs[2]), each shard walked in forward calls of '
+                    'batch=%d (BASELINE configs[1]); net+parse+SMPL per call%s' %
+                    (bb, G, world, '' if world == 1 else 's', B, ', one RCCL all-gather of the per-person records per step' if world > 1 else ''))
+    else:
+        workload = 'ROMP %s 512x512, batch=%d synthetic images per GPU per step (weak scaling); net+parse+SMPL%s' % (
+            bb, B, '+RCCL all-gather of per-person records' if world > 1 else '')
     result = {
-        'metric': 'images/sec (512x512, %s)' % ('HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'), 'value': round(total_images / dt, 2), 'unit': 'images/s',
+        'metric': 'images/sec (512x512, %s)' % bb, 'value': round(G * args.steps / dt, 2), 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as %s-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)' % args.conv_math,
         'data': 'synthetic',
-        'config': {'workload': (('ROMP HRNet-32 512x512, batch=%d synthetic images per GPU (BASELINE configs[1]); ' if args.backbone == 'hrnet32'
-                                 else 'ROMP ResNet-50 512x512 (BASELINE configs[0] model), batch=%d synthetic images per GPU; ') +
-                                'net+parse+SMPL%s') % (B, '+RCCL all-gather of per-person records' if world > 1 else ''),
-                   'batch_per_gpu': B, 'global_batch': B * world, 'persons_per_image': round(persons / (B * world), 2),
-                   'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph), 'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math, 'batch_lanes': args.split, 'parallelism': 'dp%d' % world},
+        'config': {'workload': workload, 'batch_per_call': B, 'global_batch': G, 'images_per_gpu_per_step': n_local,
+                   'ms_per_call': round(dt / args.steps / max(1, -(-n_local // B)) * 1e3, 3),
+                   'persons_per_image': round(persons / G, 2), 'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph),
+                   'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math,
+                   'parallelism': 'dp%d' % world},
     }
     if rank == 0:
+        first = images[:B]
         if not args.no_roofline:
             with torch.cuda.stream(stream):
-                roof, classes = roofline_report(model, images, lib, L)
+                roof, classes = roofline_report(model.model, first)
             result['roofline'] = roof
             result['kernel_classes'] = classes
+        if not args.no_parity:
+            with torch.cuda.stream(stream):
+                result['config'].update(parity_report(model, first, sd, smpl_model, args.center_thresh))
+        if world == 1 and not args.no_end_to_end:
+            result['end_to_end'] = end_to_end(model, lib, L, dev, B, max(8, min(32, n_local // B)), stream)
         if world == 1 and args.conv_math != 'f32' and args.backbone == 'hrnet32' and not args.no_f32_companion:
-            # the same workload with every conv on the exact-f32 MFMA kernels only, for readers who do not accept the
-            # bf16x3 split as float32 arithmetic (it passes the same 1e-4 gate): same steps, same timing discipline
+            # the same job with every conv on the exact-f32 MFMA kernels only, for readers who do not accept the split
+            # arithmetic as float32 (it passes the same 1e-4 gate): same calls, same timing discipline, fewer steps
             del model
             settings.conv_math = 'f32'
             m32 = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
@@ -410,18 +542,18 @@ def main():
                 m32.model.autotune(B)
             if args.graph:
                 m32.model.set_graph(True)
+            k32 = max(1, min(3, args.steps))
             with torch.cuda.stream(stream):
-                for _ in range(args.warmup):
-                    m32.forward_batch(images)
+                D.local_records(m32, images, lo, chunk=B)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    m32.forward_batch(images)
+                for _ in range(k32):
+                    D.local_records(m32, images, lo, chunk=B)
                 torch.cuda.synchronize(dev)
                 dt32 = time.perf_counter() - t0
-            result['f32_mfma_companion'] = {'value': round(B * args.steps / dt32, 2), 'unit': 'images/s', 'dtype': 'f32',
-                                            'ms_per_step': round(dt32 / args.steps * 1e3, 3),
-                                            'note': 'same workload, conv_math=f32 (v_mfma_f32_32x32x2_f32 only)'}
+            result['f32_mfma_companion'] = {'value': round(G * k32 / dt32, 2), 'unit': 'images/s', 'dtype': 'f32', 'steps': k32,
+                                            'ms_per_step': round(dt32 / k32 * 1e3, 3),
+                                            'note': 'same job, conv_math=f32 (v_mfma_f32_32x32x2_f32 only)'}
             del m32
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(sd, smpl_model, args.center_thresh, args.cpu_seconds)

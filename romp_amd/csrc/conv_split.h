@@ -124,7 +124,11 @@ struct SplitCfg {
     static constexpr int B_UNITS = C::TAPS * NP * K16 * 2 * C::NW;
     static constexpr int NB = (B_UNITS + 255) / 256;
     static constexpr int LDS_MAIN = A_BYTES + B_UNITS * 16 + 4 * C::NW * 4 + 16;
-    static constexpr int LDS_BYTES = LDS_MAIN + EPI_BYTES;
+    // The register-staged kernels run the epilogue's transposes THROUGH the pixel / weight regions (dead between an item's last
+    // MFMA block and the next stage's LDS write) when those are big enough: no LDS of its own, one more workgroup per CU for
+    // the small tiles.
+    static constexpr bool EPI_ALIAS = A_BYTES + B_UNITS * 16 >= EPI_BYTES;
+    static constexpr int LDS_BYTES = LDS_MAIN + (EPI_ALIAS ? 0 : EPI_BYTES);
     // LDS-DMA weight rows: [dx][piece][k16][kg][NW] units of one tap row, double-buffered
     static constexpr int SUB_UNITS = C::KW * NP * K16 * 2 * C::NW;
     static constexpr int NBD = (SUB_UNITS + 255) / 256;
@@ -214,7 +218,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    char* sE = sA + X::LDS_MAIN + wave * EPI_WAVE;     // this wave's epilogue staging tile
+    char* sE = sA + (X::EPI_ALIAS ? 0 : X::LDS_MAIN) + wave * EPI_WAVE;     // this wave's epilogue staging tile
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
@@ -341,11 +345,19 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
         if (ch == 0 && tid == 0) sQ[0] = j_after;
         __syncthreads();
         ROMP_TRACE(12);                                // barrier: all waves done reading
+        if (X::EPI_ALIAS && last) {                    // epilogue first: it stages through the (now dead) pixel / weight regions
+            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
+            ROMP_TRACE(14);
+            if (!have_next) break;
+            __syncthreads();                           // every wave is done with its staging tile
+        }
         if (pf && !(p.dbg & 2)) write_lds(last, slot ^ 1);
         ROMP_TRACE(13);                                // next stage written to LDS
         if (last) {
-            if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
-            ROMP_TRACE(14);                            // epilogue issued
+            if (!X::EPI_ALIAS) {
+                if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
+                ROMP_TRACE(14);                        // epilogue issued
+            }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll

@@ -18,21 +18,24 @@
 namespace romp {
 
 // cv::resize(INTER_CUBIC) tables for one destination coordinate, exactly as OpenCV builds them (resize.cpp: the sampling
-// position in double, the cubic weights in float with A = -0.75, then 11-bit fixed point with round-half-even).  The
-// explicit __f*_rn / __d*_rn keep hipcc from contracting a*b+c into an FMA, which OpenCV's scalar code does not do.
+// position in double, the cubic weights in float with A = -0.75, then 11-bit fixed point with round-half-even).  `fp contract(off)`
+// keeps hipcc from fusing a*b+c into an FMA, which OpenCV's scalar code does not do.
 __device__ __forceinline__ void cv_cubic_tab(int d, int src, int dst, int& s0, int (&coef)[4]) {
+#pragma clang fp contract(off)
     const double scale = 1.0 / ((double)dst / (double)src);
-    const float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    const double fd = ((double)d + 0.5) * scale - 0.5;
+    const float f = (float)fd;
     const int fl = (int)floorf(f);
-    const float x = __fsub_rn(f, (float)fl);
-    const float xp = __fadd_rn(x, 1.f), xm = __fsub_rn(1.f, x);
+    const float x = f - (float)fl;
+    const float A = -0.75f;
+    const float xp = x + 1.f, xm = 1.f - x;
     float c[4];
-    c[0] = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(-0.75f, xp), -3.75f), xp), -6.f), xp), -3.f);
-    c[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(1.25f, x), 2.25f), x), x), 1.f);
-    c[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(1.25f, xm), 2.25f), xm), xm), 1.f);
-    c[3] = __fsub_rn(__fsub_rn(__fsub_rn(1.f, c[0]), c[1]), c[2]);
+    c[0] = ((A * xp - 5.f * A) * xp + 8.f * A) * xp - 4.f * A;
+    c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    c[2] = ((A + 2.f) * xm - (A + 3.f)) * xm * xm + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) coef[k] = min(max((int)rintf(__fmul_rn(c[k], 2048.f)), -32768), 32767);
+    for (int k = 0; k < 4; ++k) coef[k] = min(max((int)rintf(c[k] * 2048.f), -32768), 32767);
     s0 = fl - 1;
 }
 
