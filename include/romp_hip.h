@@ -146,7 +146,8 @@ int  romp_net_tuned_variant(romp_net* net, int B, int op_index);
 /* Install a variant table for batch B without measuring (e.g. one saved from an earlier autotune):
  * variants[n_ops], -1 = heuristic.  An index that is not valid for its op is ROMP_EINVAL. */
 int  romp_net_set_tuned(romp_net* net, int B, const int32_t* variants, int n_ops);
-/* Time the most recent forward per op (HIP events on `stream`); ms_out_host[n_ops]. */
+/* Time a forward per op (HIP events on `stream` around every op, ops serialised on that stream): ms_out_host[n_ops] = the
+ * median of `iters` passes. */
 int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,
                       float* params_maps_nhwc, void* stream, float* ms_out_host, int iters);
 void romp_net_destroy(romp_net* net);

@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2d_kernel(ConvParams p) {
 static ConvVariant kVariantsH2d[] = {
     ROMP_CONV_VARIANT_H2D(3, 1, 2, 2, 16, 16), ROMP_CONV_VARIANT_H2D(3, 1, 2, 2, 32, 16),
     ROMP_CONV_VARIANT_H2D(3, 1, 2, 1, 16, 16), ROMP_CONV_VARIANT_H2D(3, 1, 2, 1, 32, 16),
-    ROMP_CONV_VARIANT_H2D(3, 1, 1, 2, 16, 16), ROMP_CONV_VARIANT_H2D(3, 1, 4, 1, 32, 16),
+    ROMP_CONV_VARIANT_H2D(3, 1, 1, 2, 16, 16), ROMP_CONV_VARIANT_H2D(3, 1, 4, 1, 32, 16), ROMP_CONV_VARIANT_H2D(3, 1, 1, 1, 16, 16),
+    ROMP_CONV_VARIANT_H2D(3, 1, 1, 2, 32, 16), ROMP_CONV_VARIANT_H2D(3, 1, 1, 1, 32, 16),
     ROMP_CONV_VARIANT_H2D(3, 1, 4, 2, 16, 16), ROMP_CONV_VARIANT_H2D(3, 1, 4, 2, 32, 16),
     ROMP_CONV_VARIANT_H2D(3, 1, 2, 2, 16, 32), ROMP_CONV_VARIANT_H2D(3, 1, 2, 2, 32, 32),
     ROMP_CONV_VARIANT_H2D(3, 1, 4, 1, 16, 16), ROMP_CONV_VARIANT_H2D(3, 1, 4, 1, 16, 32),

@@ -47,9 +47,13 @@ struct PipeCfg {
     static constexpr int NRES = (RES_CHUNKS * NB_I + NWV - 1) / NWV;
     static constexpr int SS_DMA_BYTES = NWV * 256;              // every wave DMAs one dword per lane per stage: scale | shift | filler
     static constexpr int OFF_W = 2 * STAGE_BYTES;               // resident weights
-    static constexpr int OFF_E = OFF_W + WRES_BYTES;            // epilogue staging tiles
-    static constexpr int OFF_S = OFF_E + NWV * EPI_WAVE;        // two scale | shift slots
+    static constexpr int OFF_E = OFF_W + WRES_BYTES;            // epilogue staging tiles ...
+    // ... unless they do not fit beside the two stage buffers (512-pixel x 64-channel tiles): then the epilogue stages through
+    // the stage buffer its item has just finished with (one extra barrier per item)
+    static constexpr bool EALIAS = OFF_E + NWV * EPI_WAVE + 2 * SS_DMA_BYTES + 16 > 160 * 1024;
+    static constexpr int OFF_S = OFF_E + (EALIAS ? 0 : NWV * EPI_WAVE);        // two scale | shift slots
     static constexpr int LDS_BYTES = OFF_S + 2 * SS_DMA_BYTES + 16;
+    static_assert(!EALIAS || STAGE_BYTES >= NWV * EPI_WAVE, "aliased epilogue staging must fit a stage buffer");
     static_assert((9 * 2 * 2 * C::NW) % 64 == 0, "weight slab must be whole DMA instructions");
     static_assert(2 * C::NW <= NWV * 64, "scale | shift fit the per-stage dword DMA");
     static_assert(NI <= 12, "one DMA piece per tap, the rest after the block");
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv_h2p_kernel(ConvParams p) {
     if (have_next) nxt = decode_item(p, q, j_next, C::NW);
     int ch = 0, buf = 0, slot = 0;
     EpiRes<MT, NT> pre;
-    const bool use_pre = p.res && p.vec_io;
+    const bool use_pre = MT * NT < 4 && p.res && p.vec_io;             // (a 2x2 tile's residual would be 64 VGPRs: loaded in the epilogue)
     const bool full_tiles = p.Ho % C::TH == 0 && p.vec_io;              // every output store of an epilogue is issued: its count is known
     wait_all_and_barrier();
     ROMP_TRACE(4);
@@ -269,8 +273,14 @@ __global__ __launch_bounds__(512, 2) void conv_h2p_kernel(ConvParams p) {
         }
         ROMP_TRACE(11);
         if (last) {
+            char* stage_e = sE;
+            if (X::EALIAS) {                                           // every wave is done reading this stage buffer: stage through it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stage_e = sBuf + buf * X::STAGE_BYTES + wave * EPI_WAVE;
+            }
             if (!(p.dbg & 4))
-                conv_epilogue<3, 1, MT, NT, TW, CK, NWV>(p, cur, acc, sS + slot * (X::SS_DMA_BYTES / 4), sE, wave, li, lh, pre, use_pre);
+                conv_epilogue<3, 1, MT, NT, TW, CK, NWV>(p, cur, acc, sS + slot * (X::SS_DMA_BYTES / 4), stage_e, wave, li, lh, pre, use_pre);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll

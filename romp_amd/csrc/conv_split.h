@@ -133,7 +133,11 @@ struct SplitCfg {
     static constexpr int SUB_UNITS = C::KW * NP * K16 * 2 * C::NW;
     static constexpr int NBD = (SUB_UNITS + 255) / 256;
     static constexpr int LDS_MAIN_DMA = A_BYTES + 2 * SUB_UNITS * 16 + 4 * C::NW * 4 + 32;
-    static constexpr int LDS_BYTES_DMA = LDS_MAIN_DMA + EPI_BYTES;
+    // DMA kernels: the epilogue's four staging tiles go into the pixel region (as many as fit) and the tap-row buffer the last
+    // sub-stage has just consumed (the other one is receiving the next item's first row)
+    static constexpr int EPI_IN_A = A_BYTES / EPI_WAVE < 4 ? A_BYTES / EPI_WAVE : 4;
+    static constexpr bool EPI_ALIAS_DMA = EPI_IN_A + SUB_UNITS * 16 / EPI_WAVE >= 4;
+    static constexpr int LDS_BYTES_DMA = LDS_MAIN_DMA + (EPI_ALIAS_DMA ? 0 : EPI_BYTES);
 };
 
 // LDS layout of a pixel's chunk.  bf16x3: [piece][CK channels].  f16x2: the H2 order, [octet][piece][8 channels], so that a
@@ -411,7 +415,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    char* sE = sA + X::LDS_MAIN_DMA + wave * EPI_WAVE;            // this wave's epilogue staging tile
+    char* sE = sA + X::LDS_MAIN_DMA + wave * EPI_WAVE;            // this wave's epilogue staging tile (unless aliased, see EPI_ALIAS_DMA)
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int n_chunks = p.cin_pad / CK;
@@ -567,11 +571,21 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
         ROMP_TRACE(12);
         bbuf ^= 1;
         if (last_row) {
+            if (X::EPI_ALIAS_DMA && last_ch) {                     // epilogue first: it stages through the pixel region and the consumed row buffer
+                char* se = wave < X::EPI_IN_A ? sA + wave * EPI_WAVE
+                                              : sB + (bbuf ^ 1) * (X::SUB_UNITS * 16) + (wave - X::EPI_IN_A) * EPI_WAVE;
+                if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, se, wave, li, lh);
+                ROMP_TRACE(14);
+                if (!have_next) break;
+                __syncthreads();                                   // every wave is done with its staging tile
+            }
             if (pfA && !(p.dbg & 2)) write_A(last_ch, slot ^ 1);
             ROMP_TRACE(13);
             if (last_ch) {
-                if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
-                ROMP_TRACE(14);
+                if (!X::EPI_ALIAS_DMA) {
+                    if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
+                    ROMP_TRACE(14);
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll

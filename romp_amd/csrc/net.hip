@@ -445,7 +445,7 @@ int romp_net_profile(romp_net* n, const float* image, int B, float* center, floa
     const size_t nops = n->ops.size();
     std::vector<hipEvent_t> ev(nops + 1);
     for (auto& e : ev) ROMP_HIP_CHECK(hipEventCreate(&e));
-    for (size_t i = 0; i < nops; ++i) ms_out[i] = 0.f;
+    std::vector<std::vector<float>> samples(nops);
     const std::vector<int>* tv = tuned_for(n, B);
     int rc = ROMP_OK;
     for (int it = 0; it < iters && rc == ROMP_OK; ++it) {
@@ -462,10 +462,16 @@ int romp_net_profile(romp_net* n, const float* image, int B, float* center, floa
         for (size_t i = 0; i < nops; ++i) {
             float ms = 0.f;
             hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-            ms_out[i] += ms / iters;
+            samples[i].push_back(ms);
         }
     }
     for (auto& e : ev) hipEventDestroy(e);
+    for (size_t i = 0; i < nops; ++i) {          // median of the passes: one pre-empted launch must not skew a class average
+        std::vector<float>& v = samples[i];
+        if (v.empty()) { ms_out[i] = 0.f; continue; }
+        std::sort(v.begin(), v.end());
+        ms_out[i] = v.size() & 1 ? v[v.size() / 2] : 0.5f * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+    }
     return rc;
 }
 

@@ -94,8 +94,11 @@ def local_records(model, images_local, img_offset, chunk=None, with_joints=True,
     n = images_local.shape[0]
     chunk = n if not chunk else int(chunk)
     recs = []
-    for c0 in range(0, n, chunk):
-        outputs, batch_ids = model.forward_batch(images_local[c0:c0 + chunk])
+    if chunk < n and hasattr(model, 'forward_chunks'):              # pipelined: network of chunk i+1 under parse + SMPL of chunk i
+        it = model.forward_chunks(images_local, chunk)
+    else:
+        it = ((*model.forward_batch(images_local[c0:c0 + chunk]), c0) for c0 in range(0, n, chunk))
+    for outputs, batch_ids, c0 in it:
         r = pack_records(outputs, batch_ids, img_offset + c0, with_joints=with_joints, with_verts=with_verts)
         if r is not None:
             recs.append(r)

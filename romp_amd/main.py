@@ -201,6 +201,56 @@ class ROMP(nn.Module):
         return outputs, batch_ids
 
 
+    @torch.no_grad()
+    def forward_chunks(self, images, chunk):
+        """[extension] forward_batch over `images` (n,512,512,3) in chunks of `chunk` images, software-pipelined: the network of
+        chunk i+1 (its own HIP stream and its own pair of output maps) runs while chunk i is parsed and meshed on the caller's
+        stream, so the host sync of the parse (the detection count) and the parse / SMPL kernels hide under the next network
+        forward.  Yields (outputs dict or None, batch_ids or None, first image index of the chunk)."""
+        dev = self.tdevice
+        n = images.shape[0]
+        starts = list(range(0, n, chunk))
+        if not hasattr(self, '_pipe'):
+            self._pipe = dict(stream=torch.cuda.Stream(dev), bufs={}, ev_net=[torch.cuda.Event(), torch.cuda.Event()],
+                              ev_free=[torch.cuda.Event(), torch.cuda.Event()])
+        P = self._pipe
+        cur = torch.cuda.current_stream(dev)
+
+        def bufs(B, par):
+            key = (B, par)
+            if key not in P['bufs']:
+                P['bufs'][key] = (torch.empty((B,) + tuple(self.model.out_shapes[0]), device=dev),
+                                  torch.empty((B,) + tuple(self.model.out_shapes[1]), device=dev))
+            return P['bufs'][key]
+
+        def launch(i):
+            x = images[starts[i]:starts[i] + chunk]
+            c, p_ = bufs(x.shape[0], i & 1)
+            P['stream'].wait_event(P['ev_free'][i & 1])           # the chunk that used this pair of maps has been parsed
+            with torch.cuda.stream(P['stream']):
+                self.model.forward_nhwc(x, c, p_)
+                P['ev_net'][i & 1].record(P['stream'])
+            return c, p_
+
+        P['ev_free'][0].record(cur)
+        P['ev_free'][1].record(cur)
+        P['stream'].wait_stream(cur)                              # the images are ready
+        pending = launch(0)
+        for i, c0 in enumerate(starts):
+            center, params = pending
+            if i + 1 < len(starts):
+                pending = launch(i + 1)
+            cur.wait_event(P['ev_net'][i & 1])
+            outputs, batch_ids = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True)
+            if outputs is not None:
+                outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])
+                if self.settings.calc_smpl:
+                    outputs = self.smpl_parser(outputs, root_align=self.settings.root_align)
+            P['ev_free'][i & 1].record(cur)
+            yield outputs, batch_ids, c0
+        cur.wait_stream(P['stream'])
+
+
 def main():
     """main.py:178-204 (image mode; video/webcam need OpenCV)."""
     args = romp_settings()

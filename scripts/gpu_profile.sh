@@ -1,6 +1,8 @@
 #!/bin/bash
-# rocprofv3 passes over bench.py (one GPU): kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in
-# their own passes (PMC never combined with sys/runtime traces).  Summaries -> gpurun_out/prof/.
+# rocprofv3 passes over bench.py (one GPU): kernel-trace stats, then FETCH_SIZE / WRITE_SIZE / utilisation counters each in
+# their own pass (PMC never combined with sys/runtime traces).  Summaries -> gpurun_out/prof/ (copy to profiles/<round>_*).
+# The profiled command is bench.py's default workload cut to 2 forward calls of 32 images per step (--global-batch 64): the
+# same kernels and variant table as the 1024-image job, a trace of a manageable size.
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/gpurun_out/prof"
 mkdir -p "$OUT"
@@ -10,7 +12,7 @@ export PYTHONUNBUFFERED=1
 # (no autotune measuring launches); ${BENCH_ARGS} e.g. "--conv-math f32" or "--workload bev"
 TUNE=/tmp/romp_tune.json
 rm -f $TUNE
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --tune-file $TUNE ${BENCH_ARGS}"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --no-end-to-end --global-batch 64 --tune-file $TUNE ${BENCH_ARGS}"
 $BENCH --steps 2 --warmup 1 --no-roofline > "$OUT/bench_plain.log" 2>&1
 echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
@@ -27,6 +29,29 @@ for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/rp_$C -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python "$REPO/scripts/summarize_pmc.py" "$f" $C > "$OUT/pmc_${C}_by_kernel.csv"
 done
+for CS in "MfmaUtil LdsUtil LdsBankConflict" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  TAG=$(echo $CS | tr ' ' '_' | cut -c1-40)
+  rm -rf /tmp/rp_multi
+  timeout 900 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/rp_multi -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$TAG.log" 2>&1
+  echo "pmc $TAG exit $?"
+  f=$(find /tmp/rp_multi -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python - "$f" $CS > "$OUT/pmc_${TAG}_by_kernel.csv" <<'PY'
+import csv, re, sys
+from collections import defaultdict
+path, counters = sys.argv[1], sys.argv[2:]
+agg = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
+with open(path) as f:
+    for row in csv.DictReader(f):
+        name = re.sub(r'\(.*$', '', row['Kernel_Name']).replace('void romp::', '').replace('romp::', '')
+        agg[name][row['Counter_Name']] += float(row['Counter_Value'])
+        if row['Counter_Name'] == counters[0]:
+            cnt[name] += 1
+print('kernel,dispatches,' + ','.join(c + '_mean' for c in counters))
+for k in sorted(agg, key=lambda k: -agg[k][counters[0]]):
+    print('"%s",%d,' % (k, cnt[k]) + ','.join('%.1f' % (agg[k][c] / max(cnt[k], 1)) for c in counters))
+PY
+done
 head -14 "$OUT/kernel_stats.csv"; head -14 "$OUT/kernel_stats_serial.csv"
-tail -3 "$OUT/bench_under_rocprof.log" | cut -c1-1500
-head -30 "$OUT/pmc_FETCH_SIZE_by_kernel.csv"; head -30 "$OUT/pmc_WRITE_SIZE_by_kernel.csv"
+tail -1 "$OUT/bench_under_rocprof.log" | cut -c1-600
+head -16 "$OUT/pmc_FETCH_SIZE_by_kernel.csv"; head -16 "$OUT/pmc_WRITE_SIZE_by_kernel.csv"
+head -12 "$OUT"/pmc_MfmaUtil*_by_kernel.csv; head -12 "$OUT"/pmc_SQ_WAVE*_by_kernel.csv

@@ -526,6 +526,34 @@ def test_forward_batch_matches_oracle(dev):
     assert ev < 1e-3
 
 
+def test_forward_chunks_pipelined_equals_forward_batch(dev):
+    """ROMP.forward_chunks (network of chunk i+1 on its own stream under parse + SMPL of chunk i, hipGraph replay, two pairs of
+    output maps) returns exactly what forward_batch returns chunk by chunk -- ragged last chunk included."""
+    import romp_amd
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh, settings.max_batch = 0, 1.3, 2
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=O.make_synthetic_smpl(0))
+    model.model.set_graph(True)
+    x = O.make_images(5, seed=9).to(dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        want = []
+        for c0 in range(0, 5, 2):
+            out, bids = model.forward_batch(x[c0:c0 + 2])
+            want.append(None if out is None else {k: v.clone() for k, v in out.items() if torch.is_tensor(v)} | {'bids': bids.clone()})
+        for rep in range(2):                                     # second pass replays the cached graphs
+            got = list(model.forward_chunks(x, 2))
+            assert [c0 for _, _, c0 in got] == [0, 2, 4]
+            for (out, bids, _), w in zip(got, want):
+                assert (out is None) == (w is None)
+                if out is not None:
+                    assert torch.equal(bids, w['bids'])
+                    for k in ('cam', 'smpl_thetas', 'smpl_betas', 'verts', 'joints', 'center_preds', 'center_confs'):
+                        assert torch.equal(out[k], w[k]), k
+        s.synchronize()
+
+
 def test_graph_cache_is_bounded(dev):
     """Graph mode with fresh output tensors on every call: the per-(batch, pointers) hipGraph cache must stay
     bounded (it is dropped and rebuilt past 32 entries) and keep producing the same maps."""
