@@ -233,6 +233,11 @@ int  romp_project(const float* joints, int N, int J, const float* cam, const flo
 int  romp_project_verts(const float* verts, int N, int V, const float* cam, const float* pad_info_host,
                         float* verts_camed, float* verts_camed_org, void* stream);
 
+/* BEV's rendering vertices (bev/post_parser.py:144-151): perspective_projection(verts, translation = cam_trans, focal 443.4,
+ * normalised by 256) with the untranslated vertex z appended, mapped to original-image pixels.  verts (N,V,3), cam_trans (N,3). */
+int  romp_bev_project_verts(const float* verts, int N, int V, const float* cam_trans, const float* pad_info_host,
+                            float* verts_camed_org, void* stream);
+
 /* ------------------------------------------------------------------ callers either side */
 
 /* img_preprocess (utils.py:16-30) on device: BGR uint8 (H,W,3) -> RGB float32 (S,S,3) 0..255, centred zero

@@ -7,14 +7,16 @@ and of the device-side steps of ``BEVv1.forward`` (bev/model.py:232-250) for BAS
 
 Network (HRNet-32 + BEV head), 3-D center parsing, per-person regression, SMPL-A / SMIL meshes,
 perspective projection, projection-based duplicate suppression and outlier removal
-(bev/post_parser.py:68-136,167-222) all run in libromp_hip.so.  Not built: the long-image "crowd"
-sliding window (bev/main.py:184-258, CPU orchestration of repeated single forwards).
+(bev/post_parser.py:68-136,167-222) all run in libromp_hip.so.  Video mode (``-t``): ByteTrack-3D association on the host
+(tracker.py) + OneEuro filters on the device (temporal.py); ``--render_mesh``: the Sim3DR rasteriser (renderer.py).
+Not built: the long-image "crowd" sliding window (bev/main.py:184-258, CPU orchestration of repeated single forwards).
 """
 import argparse
 import ctypes as C
 import os.path as osp
 import sys
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -41,7 +43,11 @@ def bev_settings(input_args=sys.argv[1:]):
     p.add_argument('--relative_scale_thresh', type=float, default=1.6)
     p.add_argument('--show_largest', action='store_true')
     p.add_argument('--calc_smpl', action='store_false')
-    p.add_argument('--render_mesh', action='store_true')
+    p.add_argument('--render_mesh', action='store_true',
+                   help='[romp_amd] off by default (the reference defaults to on with a bird view that needs its pyrender/cv2 overlays)')
+    p.add_argument('--renderer', type=str, default='sim3dr')
+    p.add_argument('--show_items', type=str, default='mesh', help="only 'mesh' is rendered on the device path")
+    p.add_argument('-sc', '--smooth_coeff', type=float, default=3.)
     p.add_argument('--show', action='store_true')
     p.add_argument('--smpl_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'SMPLA_NEUTRAL.pth'))
     p.add_argument('--smil_path', type=str, default=osp.join(osp.expanduser('~'), '.romp', 'smil_packed_info.pth'))
@@ -54,6 +60,15 @@ def bev_settings(input_args=sys.argv[1:]):
     if not torch.cuda.is_available():
         args.GPU = -1
     return args
+
+
+TAN_FOV = float(np.tan(np.radians(60 / 2.)))
+
+
+def denormalize_cam_params_to_trans(normed_cams):
+    """bev/post_parser.py:114-128 (positive_constrain False): (scale, ty, tx) -> camera-space translation."""
+    depth = (1. / (normed_cams[:, 0] * TAN_FOV + 1e-3)).unsqueeze(1)
+    return torch.cat([torch.flip(normed_cams[:, 1:], [1]) * depth * TAN_FOV, depth], 1)
 
 
 class CenterMap3D(object):
@@ -167,8 +182,8 @@ class BEV(nn.Module):
         self.settings = settings
         if settings.GPU == -1:
             raise L.RompHipError('romp_amd.bev needs a HIP device; there is no CPU fallback')
-        if settings.render_mesh or settings.temporal_optimize or settings.crowd:
-            raise NotImplementedError('rendering / temporal smoothing / crowd mode are outside the MI355X hot path')
+        if settings.crowd:
+            raise NotImplementedError('crowd mode (long-image sliding window, bev/main.py:184-258) is host orchestration outside the MI355X hot path')
         self.tdevice = determine_device(settings.GPU)
         if state_dict is None:
             state_dict = torch.load(settings.model_path, map_location='cpu')
@@ -179,6 +194,45 @@ class BEV(nn.Module):
             self.smpl_parser = SMPLA_parser(smpla_model if smpla_model is not None else settings.smpl_path,
                                             smil_model if smil_model is not None else settings.smil_path).to(self.tdevice)
         self.result_keys = ['smpl_thetas', 'smpl_betas', 'cam', 'cam_trans', 'params_pred', 'center_confs', 'pred_batch_ids']
+        if settings.temporal_optimize:                                                      # bev/main.py:117-121
+            self.OE_filters = {}
+            if not settings.show_largest:
+                from .tracker import Tracker
+                self.tracker = Tracker(det_thresh=0.12, low_conf_det_thresh=0.05, track_buffer=60, match_thresh=300, frame_rate=30)
+        if settings.render_mesh:                                                            # bev/main.py:112-114
+            from .vis import setup_renderer
+            self.renderer = setup_renderer(name=getattr(settings, 'renderer', 'sim3dr'), device=self.tdevice)
+            self.visualize_items = getattr(settings, 'show_items', 'mesh').split(',')
+
+    def temporal_optimization(self, outputs, signal_ID, image_scale=128, depth_scale=30):
+        """bev/main.py:260-287: ByteTrack-3D association on the host (tracker.py), OneEuro filters on the device (temporal.py).
+        Returns None when no confirmed track is seen in the frame."""
+        from .temporal import OneEuroBank
+        if signal_ID not in self.OE_filters:                                                # check_filter_state (utils.py:246-255)
+            if len(self.OE_filters) > 100:
+                self.OE_filters.clear()
+            self.OE_filters[signal_ID] = OneEuroBank(self.tdevice, getattr(self.settings, 'smooth_coeff', 3.), outputs['smpl_betas'].shape[1])
+        bank = self.OE_filters[signal_ID]
+        if self.settings.show_largest:
+            max_id = int(torch.argmax(outputs['cam'][:, 0]))
+            th, be, ca = (outputs[k][max_id:max_id + 1].contiguous().clone() for k in ('smpl_thetas', 'smpl_betas', 'cam'))
+            outputs['smpl_thetas'], outputs['smpl_betas'], outputs['cam'] = bank.smooth([0], th, be, ca)
+            return outputs
+        cams = outputs['cam'].cpu().numpy()
+        cam_trans = outputs['cam_trans'].cpu().numpy()
+        det_confs = outputs['center_confs'].cpu().numpy()
+        tracking_points = np.concatenate([(cams[:, [2, 1]] + 1) * image_scale, cam_trans[:, [2]] * depth_scale,
+                                          cams[:, [0]] * image_scale / 2], 1)
+        tracked_ids, results_inds = self.tracker.update(tracking_points, det_confs)
+        if len(tracked_ids) == 0:
+            return None
+        rows = torch.as_tensor(results_inds, dtype=torch.long, device=self.tdevice)
+        for key in self.result_keys:
+            outputs[key] = outputs[key][rows].contiguous()
+        outputs['smpl_thetas'], outputs['smpl_betas'], outputs['cam'] = bank.smooth(tracked_ids, outputs['smpl_thetas'],
+                                                                                    outputs['smpl_betas'], outputs['cam'])
+        outputs['track_ids'] = np.array(tracked_ids).astype(np.int32)
+        return outputs
 
     @torch.no_grad()
     def forward_batch(self, images, pad_infos=None):
@@ -215,12 +269,49 @@ class BEV(nn.Module):
                                              L.ptr(keep), L.stream_ptr(dev)))
         res.update({'cam_trans': tr, 'pj2d': pjo, 'pj2d_org': pjo})       # the reference aliases pj2d to pj2d_org
         mask = keep.bool()
-        return {k: (v[mask] if torch.is_tensor(v) and v.shape[:1] == (N,) else v) for k, v in res.items()}
+        mask_np = None
+        out = {}
+        for k, v in res.items():                        # remove_subjects (bev/post_parser.py:154-165): every per-person entry
+            if torch.is_tensor(v) and v.shape[:1] == (N,) and k != 'smpl_face':
+                v = v[mask]
+            elif isinstance(v, np.ndarray) and v.shape[:1] == (N,):
+                mask_np = mask.cpu().numpy() if mask_np is None else mask_np
+                v = v[mask_np]
+            out[k] = v
+        return out
 
     def forward(self, image, signal_ID=0, **kwargs):
         """bev/main.py:139-181 (normal images): BGR uint8 HxWx3 -> dict of numpy arrays or None."""
         input_image, image_pad_info = img_preprocess_device(image, self.tdevice)
-        res = self.forward_batch(input_image, image_pad_info.reshape(1, 6))
-        if res is None:
+        if not (self.settings.temporal_optimize or self.settings.render_mesh):
+            res = self.forward_batch(input_image, image_pad_info.reshape(1, 6))
+            return None if res is None else convert_tensor2numpy(res)
+        out = self.model(input_image)
+        if out is None:
             return None
+        res = {k: out[k] for k in self.result_keys}
+        if self.settings.temporal_optimize:                                                 # bev/main.py:162-166
+            res = self.temporal_optimization(res, signal_ID)
+            if res is None:
+                return None
+            res['cam_trans'] = denormalize_cam_params_to_trans(res['cam'])
+        if self.settings.calc_smpl:
+            verts, joints, face = self.smpl_parser(res['smpl_betas'], res['smpl_thetas'])
+            res.update({'verts': verts, 'joints': joints, 'smpl_face': face})
+            res = self._postprocess(res, 1, image_pad_info.reshape(1, 6))
+            if self.settings.render_mesh:                                                   # bev/main.py:147-150
+                res['verts_camed_org'] = self._verts_camed_org(res['verts'], res['cam_trans'], image_pad_info)
+                from .vis import rendering_romp_bev_results
+                cfgs = {'mesh_color': 'identity', 'items': self.visualize_items, 'renderer': getattr(self.settings, 'renderer', 'sim3dr')}
+                res = rendering_romp_bev_results(self.renderer, res, image, cfgs)
         return convert_tensor2numpy(res)
+
+    def _verts_camed_org(self, verts, cam_trans, pad_info):
+        lib = L.load()
+        v = verts.contiguous().float()
+        org = torch.empty_like(v)
+        pad_c = (C.c_float * 6)(*[float(x) for x in pad_info])
+        with torch.cuda.device(self.tdevice):
+            L.check(lib.romp_bev_project_verts(L.ptr(v), v.shape[0], v.shape[1], L.ptr(cam_trans.contiguous().float()), pad_c,
+                                               L.ptr(org), L.stream_ptr(self.tdevice)))
+        return org

@@ -36,6 +36,8 @@ struct ConvParams {
     int out_rs, out_bs;       // output row stride / image stride in floats (dense: Wo*out_cs, Ho*Wo*out_cs)
     unsigned long long* trace;   // nullptr, or TRACE_SLOTS words per wave: (s_memtime << 8 | event code) stamps (env ROMP_CONV_TRACE=1;
                                  // split-precision kernels only; read back with romp_conv_trace_read, scripts/conv_trace.py)
+    int* cu_slots;            // per-CU arrival counters (experiment: phase skew between the workgroups sharing a CU), or nullptr
+    int skew;                 // env ROMP_CONV_SKEW: cycles of start delay per arrival slot on a CU (0 = off)
     int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
                               // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
@@ -96,6 +98,23 @@ struct ConvCfg {                                     // NWV: waves per workgroup
 };
 
 struct Item { int b, ty, tx, n0, g; };
+
+// Experiment (ROMP_CONV_SKEW): the workgroups that share a CU start in lockstep, so all of them are in their load phase, then all
+// in their MFMA phase, ...  Delaying the k-th arrival on a CU by k * skew cycles staggers the phases.
+__device__ __forceinline__ void cu_phase_skew(const ConvParams& p) {
+    if (p.skew <= 0 || !p.cu_slots) return;
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, bits 0..31
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15; // HW_REG_XCC_ID
+        const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+        s_slot = atomicAdd(p.cu_slots + (((xcc * 8 + se) * 2 + sh) * 16 + cu), 1) & 3;
+    }
+    __syncthreads();
+    const long long t0 = clock64();
+    const long long wait = (long long)s_slot * p.skew;
+    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+}
 
 constexpr int TRACE_SLOTS = 64, TRACE_WAVES = 4096;
 // one stamp per wave (lane 0): word 0 of the wave's slot block counts the stamps, words 1.. hold them.  The kernel defines

@@ -52,6 +52,8 @@ static void collect_variants() {
 static bool g_attr_done = false;
 static int g_num_cu = 256;
 static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers without an arena
+static int* g_cu_slots = nullptr;           // ROMP_CONV_SKEW experiment: per-CU arrival counters
+static int g_skew = 0;
 static float* g_zero = nullptr;             // 256 bytes of zeros (out-of-image lanes of LDS-DMA pixel fetches)
 static unsigned long long* g_trace = nullptr;   // env ROMP_CONV_TRACE=1: per-wave phase stamps of the most recent split-precision conv launch
 
@@ -77,6 +79,8 @@ static int ensure_attrs() {
     }
     ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, QUEUE_INTS * sizeof(int)));
     ROMP_HIP_CHECK(hipMalloc((void**)&g_zero, 256));
+    { const char* e = getenv("ROMP_CONV_SKEW"); g_skew = e ? atoi(e) : 0;
+      if (g_skew > 0) { ROMP_HIP_CHECK(hipMalloc((void**)&g_cu_slots, 8 * 8 * 2 * 16 * sizeof(int))); ROMP_HIP_CHECK(hipMemset(g_cu_slots, 0, 8 * 8 * 2 * 16 * sizeof(int))); } }
     ROMP_HIP_CHECK(hipMemset(g_zero, 0, 256));
     { const char* e = getenv("ROMP_CONV_TRACE");
       if (e && atoi(e)) ROMP_HIP_CHECK(hipMalloc((void**)&g_trace, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long))); }
@@ -165,6 +169,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.wh = reinterpret_cast<const uint4*>(op.weight_h2);
     p.scale_h = op.scale_h2;
     p.zero = g_zero;
+    p.cu_slots = g_cu_slots; p.skew = g_skew;
     p.act_scale = ldexpf(1.f, op.act_shift);
     p.inv_act_scale = ldexpf(1.f, -op.act_shift);
     p.in_h2 = op.in_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.res_h2 = res && op.res_fmt == ROMP_FMT_H2;

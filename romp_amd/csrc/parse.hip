@@ -165,11 +165,36 @@ __global__ void project_verts_kernel(const float* __restrict__ verts, size_t tot
     org[i * 3 + 2] = (pz + 1.f) * pad_size / 2.f;
 }
 
+// bev/post_parser.py:68-107,144-151: ((v + t).xy / ((v + t).z + 1e-6)) * 443.4 / 256, z = v.z, then input -> original image
+__global__ void bev_project_verts_kernel(const float* __restrict__ verts, size_t total, int V, const float* __restrict__ trans,
+                                         float pad_size, float left, float top, float* __restrict__ org) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = i / V;
+    const float vz = verts[i * 3 + 2];
+    const float x = verts[i * 3] + trans[n * 3], y = verts[i * 3 + 1] + trans[n * 3 + 1], z = vz + trans[n * 3 + 2] + 1e-6f;
+    const float px = x / z * 443.4f / 256.f, py = y / z * 443.4f / 256.f;
+    org[i * 3] = (px + 1.f) * pad_size / 2.f - left;
+    org[i * 3 + 1] = (py + 1.f) * pad_size / 2.f - top;
+    org[i * 3 + 2] = (vz + 1.f) * pad_size / 2.f;
+}
+
 }  // namespace romp
 
 using namespace romp;
 
 extern "C" {
+
+int romp_bev_project_verts(const float* verts, int N, int V, const float* cam_trans, const float* pad_info_host, float* verts_camed_org,
+                           void* stream) {
+    ROMP_REQUIRE(verts && cam_trans && pad_info_host && verts_camed_org && N > 0 && V > 0, "romp_bev_project_verts: bad arguments");
+    const float top = pad_info_host[0], left = pad_info_host[2], h = pad_info_host[4], w = pad_info_host[5];
+    const size_t total = (size_t)N * V;
+    hipLaunchKernelGGL(bev_project_verts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, verts, total,
+                       V, cam_trans, h > w ? h : w, left, top, verts_camed_org);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
 
 int romp_project_verts(const float* verts, int N, int V, const float* cam, const float* pad_info_host, float* verts_camed,
                        float* verts_camed_org, void* stream) {

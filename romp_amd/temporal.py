@@ -18,21 +18,29 @@ class OneEuroBank(object):
         self.state = torch.zeros(capacity, self.stride, device=self.device)
         self.slots = {}                                   # track id -> row of self.state
 
-    def _slot(self, tid):
-        if tid not in self.slots:
-            if len(self.slots) >= self.state.shape[0]:    # utils.py:253-254 drops all filters of a source that has grown too large
-                self.slots.clear()
-                self.state.zero_()
+    def _slots_for(self, track_ids):
+        """Rows of self.state for the tracks of ONE call.  The table is cleared (utils.py:253-254 drops all filters of a source
+        that has grown too large) BEFORE any row of this call is handed out, so two tracks of a call never share a row."""
+        if len(set(track_ids)) != len(track_ids):
+            raise L.RompHipError('OneEuroBank.smooth: duplicate track ids %s' % list(track_ids))
+        if len(track_ids) > self.state.shape[0]:
+            raise L.RompHipError('OneEuroBank.smooth: %d tracks, capacity %d' % (len(track_ids), self.state.shape[0]))
+        fresh = [t for t in track_ids if t not in self.slots]
+        if len(self.slots) + len(fresh) > self.state.shape[0]:
+            self.slots.clear()
+            fresh = list(track_ids)
+        if fresh:
             used = set(self.slots.values())
-            s = next(i for i in range(self.state.shape[0]) if i not in used)
-            self.state[s].zero_()
-            self.slots[tid] = s
-        return self.slots[tid]
+            free = (i for i in range(self.state.shape[0]) if i not in used)
+            rows = [next(free) for _ in fresh]
+            self.state[torch.as_tensor(rows, device=self.device)] = 0
+            self.slots.update(zip(fresh, rows))
+        return [self.slots[t] for t in track_ids]
 
     def smooth(self, track_ids, thetas, betas, cam):
         """In place on thetas (N,72), betas (N,nb), cam (N,3) (device float32, contiguous); returns them."""
         assert thetas.is_contiguous() and betas.is_contiguous() and cam.is_contiguous() and thetas.dtype == torch.float32
-        slots = torch.tensor([self._slot(t) for t in track_ids], dtype=torch.int32, device=self.device)
+        slots = torch.tensor(self._slots_for(track_ids), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             L.check(self.lib.romp_oneeuro_smooth(L.ptr(self.state), L.ptr(slots), len(track_ids), self.n_betas, self.smooth_coeff,
                                                  L.ptr(thetas), L.ptr(betas), L.ptr(cam), L.stream_ptr(self.device)))

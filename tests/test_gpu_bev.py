@@ -80,6 +80,47 @@ def test_bev_localization_vs_oracle_and_golden(dev, golden_dir, bev_model):
     assert e3 < 1e-4 and e4 < 1e-4
 
 
+def test_bev_benchmark_batch_vs_oracle(dev):
+    """BASELINE configs[3] at the size bench.py times it (B=32, conv_math f16x2, variants autotuned AT 32): images 0 and 19 of the
+    batch -- 3-D centre maps and camera maps against the oracle (1e-4), and the detections / regressed parameters of those two
+    images against the oracle's BEV forward (same set, params 2e-4)."""
+    from romp_amd.bev import BEVv1
+    sd = BO.make_bev_state_dict(0)
+    model = BEVv1(sd, dev, center_thresh=0.1, max_batch=32, bf16x3='f16x2')
+    model.net.autotune(32, iters=1)
+    assert sum('conv_h2' in n for n in model.net.variant_names(32)) > 0
+    img = O.make_images(32, seed=4)
+    x = img.to(dev)
+    c3d, cam3d = model.localization(x)
+    pick = [0, 19]
+    xo = O.backbone_forward(sd, img[pick])
+    co, mo, _ = BO.coarse2fine_localization(sd, xo)
+    e3 = np.abs(c3d[pick].cpu().numpy() - co.numpy()).max()
+    e4 = np.abs(cam3d[pick].cpu().numpy() - mo.numpy()).max()
+    print(f'BEV B=32 f16x2, images {pick} vs oracle: center3d {e3:.3e} cam3d {e4:.3e}')
+    assert e3 < 1e-4 and e4 < 1e-4
+    # detections + regression of the two images: threshold half-way between the 12th and 13th strongest oracle maximum of image 0
+    bo, zo, so = BO.parse_3dcentermap(co, 0.0 + 1e-6)
+    s0 = np.sort(so[bo == 0])[::-1]
+    thresh = float(0.5 * (s0[min(11, len(s0) - 2)] + s0[min(12, len(s0) - 1)]))
+    model.centermap_parser.conf_thresh = thresh
+    out = model(x)
+    ref = BO.bev_forward(sd, img[pick], thresh)
+    assert out is not None and ref is not None
+    b = out['pred_batch_ids'].cpu().numpy()
+    rows = np.concatenate([np.nonzero(b == p)[0] for p in pick])
+
+    def canon(bb, zyx):
+        return np.lexsort(((zyx[:, 0] * 128 + zyx[:, 1]) * 128 + zyx[:, 2], bb))
+    zyx = out['pred_czyxs'].cpu().numpy()[rows]
+    ko = canon(np.searchsorted(pick, b[rows]), zyx)
+    kr = canon(ref['pred_batch_ids'], ref['pred_czyxs'])
+    assert np.array_equal(zyx[ko], ref['pred_czyxs'][kr]), 'detections differ'
+    e = np.abs(out['params_pred'].cpu().numpy()[rows][ko] - ref['params_pred'][kr]).max()
+    print(f'BEV B=32: {len(rows)} detections in the 2 images, params_pred max-abs vs oracle {e:.3e}')
+    assert e < 2e-4
+
+
 @pytest.mark.parametrize('B,thresh', [(1, 0.999), (3, 0.9995), (2, 0.99)])
 def test_bev_parse_vs_oracle(dev, B, thresh):
     """MaxPool3d(5) NMS + ordered top-K on random volumes incl. a plateau and the saturated case."""
@@ -150,3 +191,91 @@ def test_bev_api(dev, golden_dir):
     rs = np.random.RandomState(0)
     out = model(rs.randint(0, 256, (300, 500, 3)).astype(np.uint8))
     assert out is None or isinstance(out['verts'], np.ndarray)
+
+
+def test_bev_temporal_and_render(dev):
+    """BEV(settings: -t --render_mesh) over a short clip (bev/main.py:162-166,260-287,147-150): every reported person carries a
+    track id; thetas / betas / cam are the OneEuro-filtered values of that track (oracle filters fed with the raw per-frame
+    estimates); meshes come from the smoothed parameters; 'rendered_image' = [frame | Sim3DR rendering] equals the oracle
+    renderer on the oracle's perspective projection of the returned meshes, bit for bit."""
+    from oracle import sim3dr_oracle as SO
+    from oracle import temporal_oracle as TO
+    from romp_amd import bev, tracker
+    from romp_amd.vis import mesh_color_left2right
+    tracker.Track.last_id = 0
+    s = bev.bev_settings(['-t', '--render_mesh'])
+    s.GPU, s.center_thresh, s.max_batch = 0, 0.9995, 2
+    smpla, smil = O.make_synthetic_smpl(0, 11), O.make_synthetic_smpl(5, 10)
+    _, base_tri = SO.ellipsoid_mesh(84, 82, [0, 0, 0], [1, 1, 1])
+    faces = np.zeros((13776, 3), np.int64)
+    faces[:len(base_tri)] = base_tri
+    smpla, smil = dict(smpla, f=torch.from_numpy(faces).float()), dict(smil, f=torch.from_numpy(faces).float())
+    model = bev.BEV(s, state_dict=BO.make_bev_state_dict(0), smpla_model=smpla, smil_model=smil)
+    seen = []
+    inner = model.temporal_optimization
+
+    def spy(outputs, signal_ID):
+        raw = {k: outputs[k].clone() for k in ('smpl_thetas', 'smpl_betas', 'cam', 'params_pred')}
+        res = inner(outputs, signal_ID)
+        seen.append((raw, None if res is None else {k: (res[k].clone() if torch.is_tensor(res[k]) else res[k].copy())
+                                                   for k in ('smpl_thetas', 'smpl_betas', 'cam', 'params_pred', 'track_ids')}))
+        return res
+
+    model.temporal_optimization = spy
+    rs = np.random.RandomState(2)
+    frame0 = rs.randint(0, 256, (360, 640, 3)).astype(np.uint8)
+    from romp_amd.utils import img_preprocess_device
+    for thresh in (0.9995, 0.999, 0.99, 0.9, 0.5, 0.1):                     # the highest threshold that still sees a few persons
+        model.model.centermap_parser.conf_thresh = thresh
+        probe = model.model(img_preprocess_device(frame0, dev)[0])
+        if probe is not None and probe['cam'].shape[0] >= 3:
+            break
+    print('center threshold', thresh, 'persons on the first frame', probe['cam'].shape[0])
+    filters, all_ids = {}, set()
+    for f in range(4):
+        frame = np.clip(frame0.astype(np.int32) + rs.randint(-5, 6, frame0.shape), 0, 255).astype(np.uint8)
+        out = model(frame)
+        raw, sm = seen[-1]
+        assert sm is not None and out is not None
+        ids = sm['track_ids'].tolist()
+        assert len(set(ids)) == len(ids)
+        if f == 0:
+            assert sorted(ids) == list(range(1, len(ids) + 1))            # every first-frame detection starts a confirmed track
+        all_ids |= set(ids)
+        worst = 0.
+        for r, tid in enumerate(ids):
+            src = torch.where((raw['params_pred'] == sm['params_pred'][r]).all(1))[0]
+            assert len(src) >= 1
+            k = int(src[0])
+            flt = filters.setdefault(tid, TO.make_filters(s.smooth_coeff))
+            t, b, c = TO.smooth(flt, raw['smpl_thetas'][k].cpu(), raw['smpl_betas'][k].cpu(), raw['cam'][k].cpu())
+            worst = max(worst, float((sm['smpl_thetas'][r].cpu() - t).abs().max()), float((sm['smpl_betas'][r].cpu() - b).abs().max()),
+                        float((sm['cam'][r].cpu() - c).abs().max()))
+        print('frame %d: %d tracked persons, smoothed vs oracle filters max-abs %.3e' % (f, len(ids), worst))
+        assert worst < 5e-5
+        # what is returned: the survivors of duplicate suppression / outlier removal, ids kept in step with the rows
+        n = len(out['track_ids'])
+        assert out['cam'].shape == (n, 3) and out['verts'].shape == (n, 6890, 3) and set(out['track_ids'].tolist()) <= set(ids)
+        vo, _ = BO.smpla_forward(smpla, smil, out['smpl_betas'], out['smpl_thetas'])
+        assert np.abs(out['verts'] - vo).max() < 1e-4
+        ct = BO.cam_to_trans(out['cam'])
+        assert np.abs(out['cam_trans'] - ct).max() < 1e-4 * max(1., np.abs(ct).max())
+        # rendering
+        assert out['rendered_image'].shape == (360, 1280, 3) and np.array_equal(out['rendered_image'][:, :640], frame)
+        F32 = np.float32
+        verts, tr = out['verts'].astype(F32), out['cam_trans'].astype(F32)
+        p = verts + tr[:, None]
+        z = p[..., 2] + F32(1e-6)
+        px, py = p[..., 0] / z * F32(443.4) / F32(256), p[..., 1] / z * F32(443.4) / F32(256)
+        pad = F32(640)
+        top, left = F32((640 - 360) // 2), F32(0)
+        vorg = np.stack([(px + F32(1)) * pad / F32(2) - left, (py + F32(1)) * pad / F32(2) - top, (verts[..., 2] + F32(1)) * pad / F32(2)], -1).astype(F32)
+        order = torch.sort(torch.from_numpy(tr[:, 2]), descending=True).indices.numpy()
+        vorg = vorg[order]
+        vorg[:, :, 2] *= -1
+        colors = mesh_color_left2right(torch.from_numpy(tr))[order]
+        ref = SO.render_meshes(vorg, faces.astype(np.int32), frame, colors, use_ref=SO.load_ref() is not None)
+        nd = int((out['rendered_image'][:, 640:] != ref).sum())
+        print('   rendered_image vs oracle pipeline: differing bytes %d, painted px %d' % (nd, int((ref != frame).any(2).sum())))
+        assert nd <= 3 * 8                                                  # a vertex within 1 ulp of a pixel centre may flip a pixel
+    assert len(all_ids) >= 1
