@@ -8,11 +8,15 @@
 // 4x4 transform tensor T (N,6890,4,4 = 28 MB at N=64) -- ~10x the algorithmic traffic.  Here:
 //   kernel A (one wave per person)  Rodrigues x24, rest joints from the PRE-REGRESSED template
 //            J = J_template + J_shapedirs.beta  (algebraically J_regressor @ (v_template + S.beta),
-//            smpl.py:153-156, without the 6890-long reduction), 24-step parent chain, A matrices;
-//   kernel B (one lane per vertex, PB persons per workgroup)  shape blend + 207-term pose blend +
-//            24-joint skinning entirely in registers; posedirs (17 MB) is the only large stream and
-//            each element is used for PB persons; nothing but the final vertex is written;
-//   kernel C (one workgroup per person)  21 vertex picks + 26 regressed joints, wavefront reductions.
+//            smpl.py:153-156, without the 6890-long reduction), parent chain walked LEVEL by level of the
+//            kinematic tree (8 dependent steps for SMPL instead of 23), A matrices;
+//   kernel B (one lane per vertex, 64 vertices x PB = 16 persons per workgroup)  shape blend + 207-term pose blend +
+//            24-joint skinning in registers (packed-f32 FMAs); posedirs (17 MB) is the only large stream: the
+//            person groups of one vertex tile are placed on the SAME XCD back to back so that the tile is fetched
+//            from HBM once and re-read from that XCD's L2; the finished vertices also give this tile's share of the
+//            26 regressed joints (partial sums, one row per tile);
+//   kernel C (one workgroup per person)  sums the 108 per-tile partials in a fixed order, picks 21 vertices,
+//            optional root alignment of the joints.
 // All float32; bound = HBM (constants 20 MB once + 82.7 KB written per person).
 #include "common.h"
 #include <vector>
@@ -20,9 +24,16 @@
 namespace romp {
 
 constexpr int NV = 6890, NJ = 24, NPF = 207, NJOUT = 71, NREG = 26, NPICK = 21;
-constexpr int PB = 8;    // persons per workgroup in the skinning kernel
+constexpr int PB = 16;                                 // persons per workgroup in the skinning kernel
+constexpr int NT = (NV + 63) / 64;                    // 108 vertex tiles
+constexpr int MAXLV = NJ;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 
 struct Parents { int p[NJ]; };
+// joints ordered by depth in the kinematic tree: level l = order[start[l] .. start[l + 1])
+struct Levels { int n; int start[MAXLV + 1]; int order[NJ]; };
 
 // J_template[j][k] = sum_v Jreg[j][v] v_template[v][k];  J_shapedirs[j][k][l] = sum_v Jreg[j][v] S[v][k][l]
 __global__ __launch_bounds__(256) void smpl_prep_kernel(const float* __restrict__ Jreg, const float* __restrict__ vt,
@@ -50,16 +61,27 @@ __global__ __launch_bounds__(256) void smpl_prep_kernel(const float* __restrict_
 }
 
 // ---- kernel A: per-person pose prologue ---------------------------------------------------------
-__global__ __launch_bounds__(64) void smpl_pose_kernel(const float* __restrict__ betas, int nb,
+// pose_feat is written in the layout the skinning kernel stages: [person group][207][PB]
+template <int NB>
+__global__ __launch_bounds__(64) void smpl_pose_kernel(const float* __restrict__ betas,
                                                         const float* __restrict__ thetas,
                                                         const float* __restrict__ Jt, const float* __restrict__ Js,
-                                                        Parents par, float* __restrict__ pose_feat,
+                                                        const int* __restrict__ sched, float* __restrict__ pose_feat,
                                                         float* __restrict__ Amat, float* __restrict__ joints) {
     __shared__ float sR[NJ][9], sJ[NJ][3], sG[NJ][12];
     const int n = blockIdx.x, lane = threadIdx.x;
     if (lane < NJ) {
         const float* r = thetas + (size_t)n * 72 + lane * 3;
         const float rx0 = r[0], ry0 = r[1], rz0 = r[2];
+        float jt[3], js[3][NB], bt[NB];                      // every load of the prologue in flight before the first use
+#pragma unroll
+        for (int l = 0; l < NB; ++l) bt[l] = betas[(size_t)n * NB + l];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            jt[k] = Jt[lane * 3 + k];
+#pragma unroll
+            for (int l = 0; l < NB; ++l) js[k][l] = Js[(lane * 3 + k) * NB + l];
+        }
         const float ex = rx0 + 1e-8f, ey = ry0 + 1e-8f, ez = rz0 + 1e-8f;     // smpl.py:206
         const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
         const float rx = rx0 / angle, ry = ry0 / angle, rz = rz0 / angle;
@@ -76,25 +98,29 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 9; ++e) sR[lane][e] = R[e];
         if (lane >= 1) {
+            float* pf = pose_feat + (size_t)(n / PB) * NPF * PB + (n % PB);
 #pragma unroll
-            for (int e = 0; e < 9; ++e)
-                pose_feat[(size_t)n * NPF + (lane - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            for (int e = 0; e < 9; ++e) pf[((lane - 1) * 9 + e) * PB] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float a = Jt[lane * 3 + k];
-            for (int l = 0; l < nb; ++l) a = fmaf(betas[(size_t)n * nb + l], Js[(lane * 3 + k) * nb + l], a);
+            float a = jt[k];
+#pragma unroll
+            for (int l = 0; l < NB; ++l) a = fmaf(bt[l], js[k][l], a);
             sJ[lane][k] = a;
         }
     }
     __syncthreads();
-    // kinematic chain (smpl.py:269-275): G[i] = G[parent] * [R_i | J_i - J_parent]
-    const int rr = lane / 4, cc = lane % 4;            // lanes 0..11 own one element of the 3x4 result
+    // kinematic chain (smpl.py:269-275): G[i] = G[parent] * [R_i | J_i - J_parent], one tree level per step; five groups of
+    // 12 lanes each own one joint of the level (one element of its 3x4 transform per lane)
+    const int grp = lane / 12, el = lane % 12, rr = el / 4, cc = el % 4;
     if (lane < 12) sG[0][lane] = (cc < 3) ? sR[0][rr * 3 + cc] : sJ[0][rr];
     __syncthreads();
-    for (int i = 1; i < NJ; ++i) {
-        const int p = par.p[i];
-        if (lane < 12) {
+    const int n_lv = sched[0];
+    for (int lv = 1; lv < n_lv; ++lv) {
+        const int q1 = sched[1 + lv + 1];
+        for (int q = sched[1 + lv] + grp; q < q1 && grp < 5; q += 5) {
+            const int i = sched[1 + (MAXLV + 1) + q], p = sched[1 + (MAXLV + 1) + NJ + i];
             float v;
             if (cc < 3) {
                 v = sG[p][rr * 4 + 0] * sR[i][0 * 3 + cc];
@@ -106,7 +132,7 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float* __restrict__
                 v = fmaf(sG[p][rr * 4 + 2], sJ[i][2] - sJ[p][2], v);
                 v += sG[p][rr * 4 + 3];
             }
-            sG[i][lane] = v;
+            sG[i][el] = v;
         }
         __syncthreads();
     }
@@ -123,79 +149,137 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float* __restrict__
     }
 }
 
-// ---- kernel B: per-vertex blend shapes + skinning -----------------------------------------------
-// Workgroup = 4 waves on the SAME 64 vertices and PB persons: each wave accumulates a quarter of the 207
-// pose-blend terms (the only long dependent loop: strided posedirs loads), the partial sums meet in LDS, then
-// wave w finishes persons 2w, 2w+1 (shape blend, skinning).  4x the waves in flight of the one-wave version
-// and a 4x shorter load chain: 92 -> 33 us at N = 64.
+// ---- kernel B: per-vertex blend shapes + skinning + this tile's share of the joint regression ----------------------
+// Workgroup = 4 waves on the SAME 64 vertices and PB persons.  Each wave accumulates a quarter of the 207 pose-blend terms
+// (the only long dependent loop: strided posedirs loads), the partial sums meet in LDS, then wave w finishes persons
+// 4w .. 4w+3 (shape blend, skinning) and the workgroup reduces reg[r][tile] . vertex for the 26 regressors.
+// Workgroup id -> (tile, person group): ids that differ by 8 run on the same XCD, so the person groups of a tile get
+// consecutive slots of ONE XCD (posedirs tile: HBM once, then L2).
 constexpr int SKIN_WAVES = 4, KQ = (NPF + SKIN_WAVES - 1) / SKIN_WAVES;   // 52 terms per wave
+constexpr int PPW = PB / SKIN_WAVES;                                      // persons finished per wave
+constexpr int U_FLOATS = SKIN_WAVES * PB * 3 * 64;                        // blend partials, then the vertex tile
+constexpr int KC = 13, NCH = KQ / KC;                                     // posedirs terms per register chunk, chunks per wave
+static_assert(KQ == KC * NCH, "chunking of the pose-blend quarter");
+
+__device__ __forceinline__ void pd_load(float (&d)[KC][3], const float* __restrict__ pdv, int kbase) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const size_t off = (size_t)min(kbase + i, NPF - 1) * (NV * 3);
+        d[i][0] = pdv[off]; d[i][1] = pdv[off + 1]; d[i][2] = pdv[off + 2];
+    }
+}
+
+__device__ __forceinline__ void pd_blend(f2 (&po)[PB / 2][3], const float (&d)[KC][3], const float (*s_pf)[PB], int kbase) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const int k = kbase + i;
+        const bool in = k < NPF;                                  // the last quarter is one term short
+        const float d0 = in ? d[i][0] : 0.f, d1 = in ? d[i][1] : 0.f, d2 = in ? d[i][2] : 0.f;
+        const f2 dd0{d0, d0}, dd1{d1, d1}, dd2{d2, d2};
+        const float* row = s_pf[min(k, NPF - 1)];
+#pragma unroll
+        for (int p4 = 0; p4 < PB; p4 += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(row + p4);
+            const f2 fa{f.x, f.y}, fb{f.z, f.w};
+            po[p4 / 2][0] = pk_fma(fa, dd0, po[p4 / 2][0]); po[p4 / 2][1] = pk_fma(fa, dd1, po[p4 / 2][1]); po[p4 / 2][2] = pk_fma(fa, dd2, po[p4 / 2][2]);
+            po[p4 / 2 + 1][0] = pk_fma(fb, dd0, po[p4 / 2 + 1][0]); po[p4 / 2 + 1][1] = pk_fma(fb, dd1, po[p4 / 2 + 1][1]); po[p4 / 2 + 1][2] = pk_fma(fb, dd2, po[p4 / 2 + 1][2]);
+        }
+    }
+}
+
+// Measured alternatives (N = 64, whole SMPL call): pose features and the relative transforms read through the scalar cache
+// as SGPR operands instead of LDS (no staging, one barrier less): 44 us against 37 us -- the s_load round trips cannot be
+// prefetched deep enough with ~100 SGPRs.
+constexpr int SVS = 196, RS = 68;                                         // person / regressor strides of the LDS tiles (16-byte rows)
+constexpr int RPAIRS = NREG / 2;                                          // joint regressors in pairs, one (person, pair) per thread
+static_assert(NREG % 2 == 0 && PB * RPAIRS <= 256, "joint partials: one pass");
 template <int NB>
 __global__ __launch_bounds__(256) void smpl_skin_kernel(const float* __restrict__ betas, const float* __restrict__ pose_feat,
                                                          const float* __restrict__ Amat, const float* __restrict__ vt,
                                                          const float* __restrict__ sd, const float* __restrict__ pd,
-                                                         const float* __restrict__ lbsw, int N, float* __restrict__ verts) {
-    __shared__ __attribute__((aligned(16))) float s_pf[NPF][PB];
-    __shared__ __attribute__((aligned(16))) float s_A[PB][NJ][12];
+                                                         const float* __restrict__ lbsw, const float* __restrict__ reg, int N, int groups,
+                                                         float* __restrict__ verts, float* __restrict__ jpart, int dbg) {
+    __shared__ __attribute__((aligned(16))) float s_u[U_FLOATS];          // pose features, then blend partials, then the vertex tile
+    __shared__ __attribute__((aligned(16))) float s_A[5 * 256 * 4];       // PB x 24 x 12 (+ staging slack); later: the regressor tile [NREG][RS]
     __shared__ float s_beta[PB][NB];
-    __shared__ float s_po[SKIN_WAVES][PB * 3][64];
+    static_assert(NPF * PB <= U_FLOATS && 4 * 256 * 4 <= U_FLOATS && PB * SVS <= U_FLOATS && NREG * RS <= PB * NJ * 12 && NT % 4 == 0, "LDS aliasing");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int p0 = blockIdx.y * PB;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = (slot / groups) * 8 + xcd, grp = slot % groups;
+    if (tile >= NT) return;
+    const int p0 = grp * PB;
     const int np = min(PB, N - p0);
-    for (int idx = tid; idx < NPF * PB; idx += 256) {
-        const int k = idx / PB, p = idx % PB;
-        s_pf[k][p] = p < np ? pose_feat[(size_t)(p0 + p) * NPF + k] : 0.f;
-    }
-    for (int idx = tid; idx < PB * NJ * 12; idx += 256) {
-        const int p = idx / (NJ * 12);
-        (&s_A[0][0][0])[idx] = p < np ? Amat[(size_t)p0 * NJ * 12 + idx] : 0.f;
-    }
-    for (int idx = tid; idx < PB * NB; idx += 256) {
-        const int p = idx / NB;
-        (&s_beta[0][0])[idx] = p < np ? betas[(size_t)p0 * NB + idx] : 0.f;
-    }
-    __syncthreads();
-    const int v = min(blockIdx.x * 64 + lane, NV - 1);            // tail lanes recompute the last vertex (no divergent barrier)
-    // pose blend shapes, this wave's quarter of  pose_feature @ posedirs   (smpl.py:167-170)
-    float po[PB][3];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) po[p][0] = po[p][1] = po[p][2] = 0.f;
+    const bool live = tile * 64 + lane < NV;
+    const int v = min(tile * 64 + lane, NV - 1);                  // tail lanes recompute the last vertex
     const float* pdv = pd + (size_t)v * 3;
-    const int k0 = wave * KQ, k1 = min(NPF, k0 + KQ);
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
-        const float d0 = pdv[(size_t)k * (NV * 3) + 0], d1 = pdv[(size_t)k * (NV * 3) + 1], d2 = pdv[(size_t)k * (NV * 3) + 2];
+    const int k0 = wave * KQ;
+    // the first posedirs chunk and the staging loads leave together; nothing waits before everything is in flight
+    float d[2][KC][3];
+    pd_load(d[0], pdv, k0);
+    constexpr int PF4 = NPF * PB / 4, A4 = PB * NJ * 12 / 4;     // 828 and 1152 16-byte units, contiguous per person group
+    static_assert(PF4 <= 4 * 256 && A4 <= 5 * 256 && PB * NB <= 256, "staging loops");
+    const float4* src_pf = reinterpret_cast<const float4*>(pose_feat + (size_t)grp * NPF * PB);
+    const float4* src_A = reinterpret_cast<const float4*>(Amat + (size_t)p0 * NJ * 12);
+    float4 tpf[4], tA[5];
 #pragma unroll
-        for (int p4 = 0; p4 < PB; p4 += 4) {
-            const float4 f = *reinterpret_cast<const float4*>(&s_pf[k][p4]);
-            po[p4 + 0][0] = fmaf(f.x, d0, po[p4 + 0][0]); po[p4 + 0][1] = fmaf(f.x, d1, po[p4 + 0][1]); po[p4 + 0][2] = fmaf(f.x, d2, po[p4 + 0][2]);
-            po[p4 + 1][0] = fmaf(f.y, d0, po[p4 + 1][0]); po[p4 + 1][1] = fmaf(f.y, d1, po[p4 + 1][1]); po[p4 + 1][2] = fmaf(f.y, d2, po[p4 + 1][2]);
-            po[p4 + 2][0] = fmaf(f.z, d0, po[p4 + 2][0]); po[p4 + 2][1] = fmaf(f.z, d1, po[p4 + 2][1]); po[p4 + 2][2] = fmaf(f.z, d2, po[p4 + 2][2]);
-            po[p4 + 3][0] = fmaf(f.w, d0, po[p4 + 3][0]); po[p4 + 3][1] = fmaf(f.w, d1, po[p4 + 3][1]); po[p4 + 3][2] = fmaf(f.w, d2, po[p4 + 3][2]);
-        }
-    }
+    for (int i = 0; i < 4; ++i) tpf[i] = src_pf[min(tid + 256 * i, PF4 - 1)];
 #pragma unroll
-    for (int p = 0; p < PB; ++p)
+    for (int i = 0; i < 5; ++i) tA[i] = src_A[min(tid + 256 * i, A4 - 1)];
+    const float tb = (tid < PB * NB && tid / NB < np) ? betas[(size_t)p0 * NB + tid] : 0.f;
+    // unconditional stores (the units past the end land in slack): a predicated store would pull its load into the branch
 #pragma unroll
-        for (int k = 0; k < 3; ++k) s_po[wave][p * 3 + k][lane] = po[p][k];
+    for (int i = 0; i < 4; ++i) reinterpret_cast<float4*>(s_u)[tid + 256 * i] = tpf[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) reinterpret_cast<float4*>(s_A)[tid + 256 * i] = tA[i];
+    if (tid < PB * NB) (&s_beta[0][0])[tid] = tb;
     __syncthreads();
-    if (blockIdx.x * 64 + lane >= NV) return;
-    // this wave's persons: shape blend, sum of the pose-blend quarters, skinning
+    // pose blend shapes, this wave's quarter of  pose_feature @ posedirs   (smpl.py:167-170); persons in packed pairs,
+    // posedirs in register chunks of 13 terms, the next chunk loading while this one is used
+    const float(*s_pf)[PB] = reinterpret_cast<const float(*)[PB]>(s_u);   // [NPF][PB]
+    f2 po[PB / 2][3];
+#pragma unroll
+    for (int p = 0; p < PB / 2; ++p) po[p][0] = po[p][1] = po[p][2] = f2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH && !(dbg & 2)) pd_load(d[(c + 1) & 1], pdv, k0 + (c + 1) * KC);
+        if (!(dbg & 8)) pd_blend(po, d[c & 1], s_pf, k0 + c * KC);
+    }
+    // per-vertex constants of the finishing phase and the regressor tile: in flight across the exchange of the partials
     const float t0 = vt[v * 3 + 0], t1 = vt[v * 3 + 1], t2 = vt[v * 3 + 2];
     float sdv[3][NB];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int l = 0; l < NB; ++l) sdv[k][l] = sd[((size_t)v * 3 + k) * NB + l];
-    float w[NJ];
+    f2 w[NJ];
 #pragma unroll
     for (int j4 = 0; j4 < NJ; j4 += 4) {
         const float4 t = *reinterpret_cast<const float4*>(lbsw + (size_t)v * NJ + j4);
-        w[j4] = t.x; w[j4 + 1] = t.y; w[j4 + 2] = t.z; w[j4 + 3] = t.w;
+        w[j4] = f2{t.x, t.x}; w[j4 + 1] = f2{t.y, t.y}; w[j4 + 2] = f2{t.z, t.z}; w[j4 + 3] = f2{t.w, t.w};
     }
+    float treg[7];
+    static_assert(NREG * 64 <= 7 * 256, "regressor tile staging");
 #pragma unroll
-    for (int pp = 0; pp < PB / SKIN_WAVES; ++pp) {
-        const int p = wave * (PB / SKIN_WAVES) + pp;
-        if (p >= np) continue;
+    for (int i = 0; i < 7; ++i) {
+        const int idx = min(tid + 256 * i, NREG * 64 - 1), vv = tile * 64 + (idx & 63);
+        const float x = reg[(size_t)(idx >> 6) * NV + min(vv, NV - 1)];
+        treg[i] = vv < NV ? x : 0.f;                              // zero weight for the recomputed tail lanes
+    }
+    __syncthreads();                                              // every wave is done with the pose features: s_u becomes the partials
+    float(*s_po)[PB * 3][64] = reinterpret_cast<float(*)[PB * 3][64]>(s_u);
+#pragma unroll
+    for (int p = 0; p < PB / 2; ++p)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            s_po[wave][(2 * p) * 3 + k][lane] = po[p][k].x;
+            s_po[wave][(2 * p + 1) * 3 + k][lane] = po[p][k].y;
+        }
+    __syncthreads();
+    // this wave's persons: shape blend, sum of the pose-blend quarters, skinning
+    float out[PPW][3];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int p = wave * PPW + pp;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;            // einsum('bl,mkl->bmk') then + v_template (smpl.py:153)
 #pragma unroll
         for (int l = 0; l < NB; ++l) {
@@ -207,81 +291,123 @@ __global__ __launch_bounds__(256) void smpl_skin_kernel(const float* __restrict_
         for (int k = 0; k < 3; ++k)
             q[k] = (s_po[0][p * 3 + k][lane] + s_po[1][p * 3 + k][lane]) + (s_po[2][p * 3 + k][lane] + s_po[3][p * 3 + k][lane]);
         const float x = q[0] + (t0 + a0), y = q[1] + (t1 + a1), z = q[2] + (t2 + a2);
-        float T[12];
+        f2 T[6];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int e = 0; e < 6; ++e) T[e] = f2{0.f, 0.f};
+        const float* Ap = s_A + p * NJ * 12;
+        if (!(dbg & 4))
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {              // T = W @ A   (smpl.py:179)
-            const float4 a0v = *reinterpret_cast<const float4*>(&s_A[p][j][0]);
-            const float4 a1v = *reinterpret_cast<const float4*>(&s_A[p][j][4]);
-            const float4 a2v = *reinterpret_cast<const float4*>(&s_A[p][j][8]);
-            T[0] = fmaf(w[j], a0v.x, T[0]); T[1] = fmaf(w[j], a0v.y, T[1]); T[2] = fmaf(w[j], a0v.z, T[2]); T[3] = fmaf(w[j], a0v.w, T[3]);
-            T[4] = fmaf(w[j], a1v.x, T[4]); T[5] = fmaf(w[j], a1v.y, T[5]); T[6] = fmaf(w[j], a1v.z, T[6]); T[7] = fmaf(w[j], a1v.w, T[7]);
-            T[8] = fmaf(w[j], a2v.x, T[8]); T[9] = fmaf(w[j], a2v.y, T[9]); T[10] = fmaf(w[j], a2v.z, T[10]); T[11] = fmaf(w[j], a2v.w, T[11]);
+            const float4 a0v = *reinterpret_cast<const float4*>(Ap + j * 12);
+            const float4 a1v = *reinterpret_cast<const float4*>(Ap + j * 12 + 4);
+            const float4 a2v = *reinterpret_cast<const float4*>(Ap + j * 12 + 8);
+            T[0] = pk_fma(w[j], f2{a0v.x, a0v.y}, T[0]); T[1] = pk_fma(w[j], f2{a0v.z, a0v.w}, T[1]);
+            T[2] = pk_fma(w[j], f2{a1v.x, a1v.y}, T[2]); T[3] = pk_fma(w[j], f2{a1v.z, a1v.w}, T[3]);
+            T[4] = pk_fma(w[j], f2{a2v.x, a2v.y}, T[4]); T[5] = pk_fma(w[j], f2{a2v.z, a2v.w}, T[5]);
         }
-        float* o = verts + ((size_t)(p0 + p) * NV + v) * 3;   // v_homo = T @ [v_posed,1]  (smpl.py:185)
-        o[0] = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
-        o[1] = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
-        o[2] = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
-    }
-}
-
-// ---- kernel C: joint regression ---------------------------------------------------------------
-// One workgroup per (person, quarter of the 26 regressed joints): at N = 64 a workgroup per person left three quarters
-// of the CUs idle and made this the longest SMPL kernel.
-constexpr int JSPLIT = 4, RPS = (NREG + JSPLIT - 1) / JSPLIT;          // 7 regressors per workgroup
-__global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restrict__ verts, const float* __restrict__ reg,
-                                                           const int* __restrict__ pick, float* __restrict__ joints) {
-    __shared__ float s_part[4][RPS * 3];
-    const int n = blockIdx.x, r0 = blockIdx.y * RPS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nr = min(RPS, NREG - r0);
-    const float* vn = verts + (size_t)n * NV * 3;
-    float acc[RPS][3];
-#pragma unroll
-    for (int r = 0; r < RPS; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
-    for (int v = tid; v < NV; v += 256) {
-        const float x = vn[v * 3], y = vn[v * 3 + 1], z = vn[v * 3 + 2];
-#pragma unroll
-        for (int r = 0; r < RPS; ++r) {
-            const float w = reg[(size_t)min(r0 + r, NREG - 1) * NV + v];
-            acc[r][0] = fmaf(w, x, acc[r][0]); acc[r][1] = fmaf(w, y, acc[r][1]); acc[r][2] = fmaf(w, z, acc[r][2]);
+        out[pp][0] = fmaf(T[0].x, x, fmaf(T[0].y, y, fmaf(T[1].x, z, T[1].y)));   // v_homo = T @ [v_posed,1]  (smpl.py:185)
+        out[pp][1] = fmaf(T[2].x, x, fmaf(T[2].y, y, fmaf(T[3].x, z, T[3].y)));
+        out[pp][2] = fmaf(T[4].x, x, fmaf(T[4].y, y, fmaf(T[5].x, z, T[5].y)));
+        if (live && p < np) {
+            float* o = verts + ((size_t)(p0 + p) * NV + v) * 3;
+            o[0] = out[pp][0]; o[1] = out[pp][1]; o[2] = out[pp][2];
         }
     }
+    __syncthreads();                                              // partials and A are consumed: vertex tile + regressor tile
 #pragma unroll
-    for (int r = 0; r < RPS; ++r)
+    for (int pp = 0; pp < PPW; ++pp)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float a = acc[r][k];
-            for (int d = 32; d > 0; d >>= 1) a += __shfl_xor(a, d);
-            if (lane == 0) s_part[wave][r * 3 + k] = a;
-        }
+        for (int k = 0; k < 3; ++k) s_u[(wave * PPW + pp) * SVS + k * 64 + lane] = out[pp][k];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < NREG * 64) s_A[(idx >> 6) * RS + (idx & 63)] = treg[i];
+    }
     __syncthreads();
-    float* jn = joints + (size_t)n * NJOUT * 3;
-    if (tid < nr * 3)                                        // joints 45..70: extra9 then h36m17 (smpl.py:26-29)
-        jn[(NJ + NPICK + r0) * 3 + tid] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
-    if (blockIdx.y == 0 && tid < NPICK * 3)                  // joints 24..44: vertex picks (smpl.py:25)
-        jn[NJ * 3 + tid] = vn[pick[tid / 3] * 3 + tid % 3];
+    // joints 45..70 (extra9 then h36m17, smpl.py:26-29): this tile's 64 terms of  regressor @ vertices; one thread per
+    // (person, regressor pair), 16-byte LDS reads along the vertices
+    if (tid < PB * RPAIRS && !(dbg & 1)) {
+        const int p = tid % PB, rp = tid / PB;
+        const float* sv = s_u + p * SVS;
+        const float* sr = s_A + rp * 2 * RS;
+        f2 acc[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};  // [component] over the regressor pair
+#pragma unroll 4
+        for (int i = 0; i < 64; i += 4) {
+            const float4 x4 = *reinterpret_cast<const float4*>(sv + i), y4 = *reinterpret_cast<const float4*>(sv + 64 + i),
+                         z4 = *reinterpret_cast<const float4*>(sv + 128 + i);
+            const float4 r0 = *reinterpret_cast<const float4*>(sr + i), r1 = *reinterpret_cast<const float4*>(sr + RS + i);
+#define JSTEP(c)                                                             \
+            acc[0] = pk_fma(f2{r0.c, r1.c}, f2{x4.c, x4.c}, acc[0]);        \
+            acc[1] = pk_fma(f2{r0.c, r1.c}, f2{y4.c, y4.c}, acc[1]);        \
+            acc[2] = pk_fma(f2{r0.c, r1.c}, f2{z4.c, z4.c}, acc[2]);
+            JSTEP(x) JSTEP(y) JSTEP(z) JSTEP(w)
+#undef JSTEP
+        }
+        if (p < np) {
+            float* o = jpart + (((size_t)(p0 + p) * NT + tile) * NREG + rp * 2) * 3;
+            o[0] = acc[0].x; o[1] = acc[1].x; o[2] = acc[2].x;
+            o[3] = acc[0].y; o[4] = acc[1].y; o[5] = acc[2].y;
+        }
+    }
 }
 
-// root alignment (smpl.py:102-106): root = joints[45:47].mean(0); joints -= root (vertices: smpl_root_sub_kernel)
-__global__ __launch_bounds__(256) void smpl_root_joints_kernel(float* __restrict__ joints, float* __restrict__ root) {
-    __shared__ float s_root[3];
+// ---- kernel C: joints 24..70 + optional root alignment ------------------------------------------
+// One workgroup per person: the 108 per-tile partial sums are added in tile order (deterministic), the 21 picked
+// vertices copied; with root alignment (smpl.py:102-106) root = joints[45:47].mean(0) is subtracted from all 71 joints
+// here and from the vertices by smpl_root_sub_kernel.
+__global__ __launch_bounds__(256) void smpl_joints_kernel(const float* __restrict__ verts, const float* __restrict__ jpart,
+                                                           const int* __restrict__ pick, int root_align, float* __restrict__ joints,
+                                                           float* __restrict__ root) {
+    __shared__ float s_j[NJOUT * 3];
     const int n = blockIdx.x, tid = threadIdx.x;
+    const float* vn = verts + (size_t)n * NV * 3;
     float* jn = joints + (size_t)n * NJOUT * 3;
-    if (tid < 3) {
-        const float r0 = (jn[45 * 3 + tid] + jn[46 * 3 + tid]) / 2.f;
-        s_root[tid] = r0;
-        root[n * 3 + tid] = r0;
+    __shared__ float s_part[3][NREG * 3];
+    static_assert(NT % 3 == 0 && 3 * NREG * 3 <= 256 && NREG * 3 + NPICK * 3 + NJ * 3 <= 256, "thread roles");
+    if (tid < 3 * NREG * 3) {                                // 78 outputs x 3 thirds of the tiles, every load in flight at once
+        const int e = tid % (NREG * 3), part = tid / (NREG * 3);
+        const float* src = jpart + ((size_t)n * NT + part * (NT / 3)) * NREG * 3 + e;
+        float t[NT / 3];
+#pragma unroll
+        for (int u = 0; u < NT / 3; ++u) t[u] = src[(size_t)u * NREG * 3];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NT / 3; ++u) acc[u & 3] += t[u];
+        s_part[part][e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     __syncthreads();
-    if (tid < NJOUT * 3) jn[tid] -= s_root[tid % 3];
+    if (tid < NREG * 3) {
+        s_j[(NJ + NPICK) * 3 + tid] = (s_part[0][tid] + s_part[1][tid]) + s_part[2][tid];
+    } else if (tid < NREG * 3 + NPICK * 3) {
+        const int e = tid - NREG * 3;
+        s_j[NJ * 3 + e] = vn[pick[e / 3] * 3 + e % 3];       // joints 24..44: vertex picks (smpl.py:25)
+    } else if (tid < NREG * 3 + NPICK * 3 + NJ * 3) {
+        const int e = tid - NREG * 3 - NPICK * 3;
+        s_j[e] = jn[e];                                      // joints 0..23 come from the pose kernel
+    }
+    __syncthreads();
+    if (tid < NJOUT * 3) {
+        float v = s_j[tid];
+        if (root_align) {
+            const float r0 = (s_j[45 * 3 + tid % 3] + s_j[46 * 3 + tid % 3]) / 2.f;
+            v -= r0;
+            if (tid < 3) root[n * 3 + tid] = r0;
+        }
+        if (root_align || tid >= NJ * 3) jn[tid] = v;
+    }
 }
 
-__global__ void smpl_root_sub_kernel(float* __restrict__ verts, const float* __restrict__ root, size_t total) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t n = i / (NV * 3);
-        verts[i] -= root[n * 3 + (i % 3)];
-    }
+__global__ __launch_bounds__(256) void smpl_root_sub_kernel(float* __restrict__ verts, const float* __restrict__ root) {
+    const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;       // one float2 per lane
+    static_assert(NV * 3 % 2 == 0, "person stride is a whole number of float2");
+    if (i >= NV * 3 / 2) return;
+    const float r0 = root[n * 3], r1 = root[n * 3 + 1], r2 = root[n * 3 + 2];
+    float2* p = reinterpret_cast<float2*>(verts + (size_t)n * NV * 3) + i;
+    float2 t = *p;
+    const int c = (i * 2) % 3;                                          // component of t.x
+    t.x -= c == 0 ? r0 : (c == 1 ? r1 : r2);
+    t.y -= c == 0 ? r1 : (c == 1 ? r2 : r0);
+    *p = t;
 }
 
 }  // namespace romp
@@ -292,6 +418,9 @@ struct smpl_ctx {
     int nb = 10;
     int cap = 0;
     Parents par;
+    int dbg = 0;                   // ROMP_SMPL_DBG: phase knock-outs for timing experiments (results are wrong when set)
+    int* sched = nullptr;          // [n_levels, start[MAXLV + 1], order[NJ], parent[NJ]] for the pose kernel
+    float* jpart = nullptr;        // (cap, NT, NREG, 3) per-tile joint partial sums
     float *vt = nullptr, *sd = nullptr, *pd = nullptr, *lbsw = nullptr, *reg = nullptr, *Jt = nullptr, *Js = nullptr;
     int* pick = nullptr;
     float *pose_feat = nullptr, *Amat = nullptr, *root = nullptr;
@@ -302,12 +431,17 @@ static int smpl_reserve(smpl_ctx* c, int N) {
     if (c->pose_feat) hipFree(c->pose_feat);
     if (c->Amat) hipFree(c->Amat);
     if (c->root) hipFree(c->root);
-    c->pose_feat = c->Amat = c->root = nullptr;
+    if (c->jpart) hipFree(c->jpart);
+    c->pose_feat = c->Amat = c->root = c->jpart = nullptr;
     c->cap = 0;
-    ROMP_HIP_CHECK(hipMalloc((void**)&c->pose_feat, (size_t)N * NPF * 4));
-    ROMP_HIP_CHECK(hipMalloc((void**)&c->Amat, (size_t)N * NJ * 12 * 4));
-    ROMP_HIP_CHECK(hipMalloc((void**)&c->root, (size_t)N * 3 * 4));
-    c->cap = N;
+    const size_t cap = (size_t)(N + PB - 1) / PB * PB;        // whole person groups: the skinning kernel stages PB persons at a time
+    ROMP_HIP_CHECK(hipMalloc((void**)&c->pose_feat, cap * NPF * 4));
+    ROMP_HIP_CHECK(hipMalloc((void**)&c->Amat, cap * NJ * 12 * 4));
+    ROMP_HIP_CHECK(hipMalloc((void**)&c->root, cap * 3 * 4));
+    ROMP_HIP_CHECK(hipMalloc((void**)&c->jpart, cap * NT * NREG * 3 * 4));
+    ROMP_HIP_CHECK(hipMemset(c->pose_feat, 0, cap * NPF * 4));   // rows of a partial last group stay finite
+    ROMP_HIP_CHECK(hipMemset(c->Amat, 0, cap * NJ * 12 * 4));
+    c->cap = (int)cap;
     return ROMP_OK;
 }
 
@@ -323,6 +457,7 @@ int smpl_ctx_create(smpl_ctx** out, const float* v_template, const float* shaped
     hipStream_t st = (hipStream_t)stream;
     smpl_ctx* c = new smpl_ctx();
     c->nb = n_betas;
+    if (const char* e = getenv("ROMP_SMPL_DBG")) c->dbg = atoi(e);
     for (int j = 0; j < NJ; ++j) {
         c->par.p[j] = (int)parents_host[j];
         if (j > 0 && (c->par.p[j] < 0 || c->par.p[j] >= j)) {
@@ -331,6 +466,20 @@ int smpl_ctx_create(smpl_ctx** out, const float* v_template, const float* shaped
             return ROMP_EINVAL;
         }
     }
+    // kinematic tree by depth (parents precede children, so one pass gives the depths)
+    int sched_h[1 + (MAXLV + 1) + 2 * NJ] = {0}, depth[NJ] = {0}, n_lv = 1;
+    for (int j = 1; j < NJ; ++j) {
+        depth[j] = depth[c->par.p[j]] + 1;
+        if (depth[j] + 1 > n_lv) n_lv = depth[j] + 1;
+    }
+    sched_h[0] = n_lv;
+    for (int lv = 0, q = 0; lv < n_lv; ++lv) {
+        sched_h[1 + lv] = q;
+        for (int j = 0; j < NJ; ++j)
+            if (depth[j] == lv) sched_h[1 + (MAXLV + 1) + q++] = j;
+        sched_h[1 + lv + 1] = q;
+    }
+    for (int j = 0; j < NJ; ++j) sched_h[1 + (MAXLV + 1) + NJ + j] = j ? c->par.p[j] : 0;
     int pick_h[NPICK];
     for (int i = 0; i < NPICK; ++i) {
         pick_h[i] = (int)extra_idx_host[i];
@@ -351,7 +500,8 @@ int smpl_ctx_create(smpl_ctx** out, const float* v_template, const float* shaped
     SMPL_ALLOC_COPY(c->lbsw, lbs_weights, (size_t)NV * NJ);
 #undef SMPL_ALLOC_COPY
     if (hipMalloc((void**)&c->reg, (size_t)NREG * NV * 4) != hipSuccess || hipMalloc((void**)&c->Jt, NJ * 3 * 4) != hipSuccess ||
-        hipMalloc((void**)&c->Js, (size_t)NJ * 3 * n_betas * 4) != hipSuccess || hipMalloc((void**)&c->pick, NPICK * 4) != hipSuccess) {
+        hipMalloc((void**)&c->Js, (size_t)NJ * 3 * n_betas * 4) != hipSuccess || hipMalloc((void**)&c->pick, NPICK * 4) != hipSuccess ||
+        hipMalloc((void**)&c->sched, sizeof(sched_h)) != hipSuccess) {
         set_error("smpl_ctx_create: hipMalloc failed");
         smpl_ctx_destroy(c);
         return ROMP_ENOMEM;
@@ -359,6 +509,7 @@ int smpl_ctx_create(smpl_ctx** out, const float* v_template, const float* shaped
     hipMemcpyAsync(c->reg, J_regressor_extra9, (size_t)9 * NV * 4, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(c->reg + (size_t)9 * NV, J_regressor_h36m17, (size_t)17 * NV * 4, hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(c->pick, pick_h, NPICK * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->sched, sched_h, sizeof(sched_h), hipMemcpyHostToDevice, st);
     hipLaunchKernelGGL(smpl_prep_kernel, dim3(NJ, 3 * (n_betas + 1)), dim3(256), 0, st, J_regressor, c->vt, c->sd, n_betas,
                        c->Jt, c->Js);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
@@ -380,25 +531,24 @@ int smpl_forward(smpl_ctx* c, const float* betas, int n_betas, const float* thet
     int rc = smpl_reserve(c, N);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(smpl_pose_kernel, dim3(N), dim3(64), 0, st, betas, c->nb, thetas, c->Jt, c->Js, c->par,
-                       c->pose_feat, c->Amat, joints);
+    if (c->nb == 10)
+        hipLaunchKernelGGL(smpl_pose_kernel<10>, dim3(N), dim3(64), 0, st, betas, thetas, c->Jt, c->Js, c->sched, c->pose_feat, c->Amat, joints);
+    else
+        hipLaunchKernelGGL(smpl_pose_kernel<11>, dim3(N), dim3(64), 0, st, betas, thetas, c->Jt, c->Js, c->sched, c->pose_feat, c->Amat, joints);
     ROMP_HIP_CHECK(hipGetLastError());
-    dim3 grid((NV + 63) / 64, (N + PB - 1) / PB);
+    const int groups = (N + PB - 1) / PB;
+    const dim3 grid(8 * ((NT + 7) / 8) * groups);
     if (c->nb == 10)
         hipLaunchKernelGGL(smpl_skin_kernel<10>, grid, dim3(256), 0, st, betas, c->pose_feat, c->Amat, c->vt, c->sd, c->pd,
-                           c->lbsw, N, verts);
+                           c->lbsw, c->reg, N, groups, verts, c->jpart, c->dbg);
     else
         hipLaunchKernelGGL(smpl_skin_kernel<11>, grid, dim3(256), 0, st, betas, c->pose_feat, c->Amat, c->vt, c->sd, c->pd,
-                           c->lbsw, N, verts);
+                           c->lbsw, c->reg, N, groups, verts, c->jpart, c->dbg);
     ROMP_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(smpl_joints_kernel, dim3(N, JSPLIT), dim3(256), 0, st, verts, c->reg, c->pick, joints);
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(N), dim3(256), 0, st, verts, c->jpart, c->pick, root_align, joints, c->root);
     ROMP_HIP_CHECK(hipGetLastError());
     if (root_align) {
-        hipLaunchKernelGGL(smpl_root_joints_kernel, dim3(N), dim3(256), 0, st, joints, c->root);
-        const size_t total = (size_t)N * NV * 3;
-        size_t blocks = (total + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(smpl_root_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, st, verts, c->root, total);
+        hipLaunchKernelGGL(smpl_root_sub_kernel, dim3((NV * 3 / 2 + 255) / 256, N), dim3(256), 0, st, verts, c->root);
         ROMP_HIP_CHECK(hipGetLastError());
     }
     return ROMP_OK;
@@ -406,10 +556,11 @@ int smpl_forward(smpl_ctx* c, const float* betas, int n_betas, const float* thet
 
 void smpl_ctx_destroy(smpl_ctx* c) {
     if (!c) return;
-    float* ptrs[] = {c->vt, c->sd, c->pd, c->lbsw, c->reg, c->Jt, c->Js, c->pose_feat, c->Amat, c->root};
+    float* ptrs[] = {c->vt, c->sd, c->pd, c->lbsw, c->reg, c->Jt, c->Js, c->pose_feat, c->Amat, c->root, c->jpart};
     for (float* p : ptrs)
         if (p) hipFree(p);
     if (c->pick) hipFree(c->pick);
+    if (c->sched) hipFree(c->sched);
     delete c;
 }
 
