@@ -73,6 +73,9 @@ const char* romp_last_error(void);
 #define ROMP_OP_STEM7     9     /* (x/255-mean)/std + conv7x7 s2 p3 (Cin=3) + BN + ReLU   (romp/lib/models/resnet_50.py:32-44,56) */
 #define ROMP_OP_MAXPOOL   10    /* MaxPool2d(3, 2, 1) on NHWC                             (resnet_50.py:45,56)                   */
 #define ROMP_OP_CONV3D    8     /* 3x3x3 conv Cin->Cin (1|3) on (B,C,64,128,128) + scale/shift (+res) (+ReLU)     */
+#define ROMP_OP_KSUM      11    /* tail of a split-K conv (single-image latency plans): in_buf holds `groups` float32 partial sums of
+                                   Cout channels each per pixel (a grouped ROMP_OP_CONV over input-channel slices wrote them);
+                                   y = scale * sum_g partial_g + shift (+res) (+ReLU), H x W = the OUTPUT size                  */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 typedef struct romp_op {
@@ -227,6 +230,13 @@ void smpl_ctx_destroy(smpl_ctx* ctx);
  * pj2d (N,J,2) normalised, pj2d_org (N,J,2) original-image pixels, cam_trans (N,3). */
 int  romp_project(const float* joints, int N, int J, const float* cam, const float* pad_info_host,
                   float* pj2d, float* pj2d_org, float* cam_trans, void* stream);
+
+/* convert_cam_to_3d_trans2 (post_parser.py:96-101) with the reference's linear least-squares estimator
+ * (estimate_translation_np, utils.py:347-389: its path when OpenCV's PnP is not available): joints (N,J,3), the first K
+ * of them against their normalised orthographic projections pj2d (N,J,2) mapped to (pj2d + 1) * img_size / 2 pixels
+ * -> trans (N,3); (-1,-1,-1) for a singular system. */
+int  romp_estimate_translation(const float* joints, int N, int J, int K, const float* pj2d, float focal_length,
+                               float img_size, float* trans, void* stream);
 
 /* Vertices of the meshes for rendering: verts_camed = batch_orth_proj(verts, cam, '3d', keep_dim) and its
  * original-image version (post_parser.py:81-88,108,113).  verts (N,V,3); verts_camed may be NULL. */

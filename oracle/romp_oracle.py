@@ -383,6 +383,28 @@ def convert_cam_to_3d_trans(cams, weight=2.0):
     return (np.stack([tx / s, ty / s, 1.0 / s], 1) * weight).astype(np.float32)
 
 
+def estimate_translation_np(joints_3d, joints_2d, focal_length=443.4, img_size=512.0):
+    """estimate_translation (utils.py:391-434) for one person, OpenCV absent: a joint counts when its 2-D row coordinate is
+    > -2 pixels (`joints_conf = joints_2d[:, :, -1] > -2.` reads the LAST coordinate of a 2-column array, :405-406) and its
+    depth is not the -2 sentinel; fewer than 4 such joints -> INVALID_TRANS (-1,-1,-1), else estimate_translation_np
+    (:347-389, unit weights): the t minimising || f (X + t)_xy - (uv - c) (X + t)_z ||, i.e. the least squares  Q t = c  with
+    rows (f, 0, cx - u) and (0, f, cy - v).  joints_3d (K,3), joints_2d (K,2) in pixels.  Pinned by
+    tests/golden/translation_lsq.npz (oracle/make_golden_translation.py)."""
+    X = np.asarray(joints_3d, np.float64)
+    uv = np.asarray(joints_2d, np.float64)
+    valid = (np.asarray(joints_2d)[:, -1] > -2.) & (np.asarray(joints_3d)[:, -1] != -2.)
+    if valid.sum() < 4:
+        return -np.ones(3, np.float32)
+    X, uv = X[valid], uv[valid]
+    K = X.shape[0]
+    f = np.full(2 * K, float(focal_length))
+    centre = np.tile(np.array([img_size / 2.0, img_size / 2.0]), K)
+    Z = np.repeat(X[:, 2], 2)
+    Q = np.stack([f * np.tile([1.0, 0.0], K), f * np.tile([0.0, 1.0], K), centre - uv.reshape(-1)], 1)
+    c = (uv.reshape(-1) - centre) * Z - f * X[:, :2].reshape(-1)
+    return np.linalg.solve(Q.T @ Q, Q.T @ c).astype(np.float32)
+
+
 # --------------------------------------------------------------------------------------
 # SMPL (smpl.py:62-108, 111-290)
 # --------------------------------------------------------------------------------------

@@ -39,10 +39,11 @@ def _host_floats(P: Program, values):
     return C.cast(arr, C.c_void_p).value
 
 
-def build_bev_hrnet32(sd, device, input_size=512, bf16x3=False) -> Program:
+def build_bev_hrnet32(sd, device, input_size=512, bf16x3=False, split_k_items=0) -> Program:
     assert input_size == 512, 'the BEV head is defined on a 128x128 map (bev/model.py:117)'
     sd = _clean(sd)
     P = Program(device)
+    P.split_k_items = split_k_items                           # > 0: single-image plan (plan.Program.conv)
     set_conv_math(P, bf16x3)
     x = build_hrnet32_backbone(P, sd, input_size, out_cstride=32)          # (B,128,128,32)
 

@@ -152,6 +152,13 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(out, "fusesum: bad out buffer %d", op.out_buf);
             return launch_fusesum(t, op.n_terms, out, B, op.H, op.W, op.Cout, op.out_cstride, op.out_coff, op.relu, st, op.out_fmt, op.act_shift);
         }
+        case ROMP_OP_KSUM: {
+            const float* part = resolve_in(n, op.in_buf, image);
+            const float* res = op.res_buf == ROMP_BUF_NONE ? nullptr : resolve_in(n, op.res_buf, image);
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(part && out && (op.res_buf == ROMP_BUF_NONE || res), "ksum: bad buffers %d -> %d", op.in_buf, op.out_buf);
+            return launch_ksum(op, part, res, out, B, st);
+        }
         case ROMP_OP_FORK:
         case ROMP_OP_JOIN:
             return ROMP_OK;              // stream markers: handled by run_all
@@ -527,6 +534,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     ROMP_REQUIRE(op && out && n > 0 && B > 0, "romp_conv_describe: bad arguments");
     if (op->kind == ROMP_OP_STEM) { snprintf(out, n, "stem_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FUSESUM) { snprintf(out, n, "fusesum"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_KSUM) { snprintf(out, n, "ksum"); return ROMP_OK; }
     if (op->kind == ROMP_OP_STEM7) { snprintf(out, n, "stem7_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_MAXPOOL) { snprintf(out, n, "maxpool3s2"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }

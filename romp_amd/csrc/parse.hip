@@ -149,6 +149,46 @@ __global__ void project_kernel(const float* __restrict__ joints, int N, int J, c
     }
 }
 
+// Camera translation that best explains the orthographic projection under the perspective camera: the reference's
+// estimate_translation with OpenCV absent (utils.py:391-434 -> estimate_translation_np :347-389, unit weights) over the
+// first K joints.  A joint counts when its pixel ROW coordinate is > -2 (`joints_conf = joints_2d[:, :, -1] > -2.`, :405-406,
+// reads the last coordinate of a 2-column array) and its depth is not the -2 sentinel; fewer than 4 -> INVALID_TRANS (-1).
+// Rows (f, 0, cx - u | (u - cx) Z - f X) and (0, f, cy - v | (v - cy) Z - f Y); the 3x3 normal equations in double.
+// One 64-lane workgroup per person.
+__global__ __launch_bounds__(64) void translation_lsq_kernel(const float* __restrict__ joints, int J, int K, const float* __restrict__ pj2d,
+                                                               double f, double cx, double cy, float* __restrict__ trans) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    double a02 = 0, a12 = 0, a22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    int cnt = 0;
+    for (int k = lane; k < K; k += 64) {
+        const float* X = joints + ((size_t)n * J + k) * 3;
+        const float uf = (pj2d[((size_t)n * J + k) * 2] + 1.f) * (float)cx, vf = (pj2d[((size_t)n * J + k) * 2 + 1] + 1.f) * (float)cy;   // float32, like (pj + 1) * 256
+        if (!(vf > -2.f) || X[2] == -2.f) continue;
+        ++cnt;
+        const double u = uf, v = vf;
+        const double qx = cx - u, qy = cy - v;
+        const double rx = (u - cx) * (double)X[2] - f * (double)X[0], ry = (v - cy) * (double)X[2] - f * (double)X[1];
+        a02 += f * qx; a12 += f * qy; a22 += qx * qx + qy * qy;
+        b0 += f * rx; b1 += f * ry; b2 += qx * rx + qy * ry;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        a02 += __shfl_xor(a02, d); a12 += __shfl_xor(a12, d); a22 += __shfl_xor(a22, d);
+        b0 += __shfl_xor(b0, d); b1 += __shfl_xor(b1, d); b2 += __shfl_xor(b2, d);
+        cnt += __shfl_xor(cnt, d);
+    }
+    if (lane == 0) {
+        // A = [[d, 0, a02], [0, d, a12], [a02, a12, a22]] with d = count * f^2: eliminate the first two unknowns
+        const double d = (double)cnt * f * f;
+        const double piv = a22 - (a02 * a02 + a12 * a12) / d;
+        float t0 = -1.f, t1 = -1.f, t2 = -1.f;
+        if (cnt >= 4 && fabs(piv) > 1e-12 * fabs(a22)) {
+            const double z = (b2 - (a02 * b0 + a12 * b1) / d) / piv;
+            t0 = (float)((b0 - a02 * z) / d); t1 = (float)((b1 - a12 * z) / d); t2 = (float)z;
+        }
+        trans[n * 3] = t0; trans[n * 3 + 1] = t1; trans[n * 3 + 2] = t2;
+    }
+}
+
 // batch_orth_proj(mode='3d', keep_dim=True) + convert_proejection_from_input_to_orgimg on (N,V,3) vertices
 // (post_parser.py:81-88,108,113; utils.py:309-315): x,y projected, z kept; then all three to original-image pixels.
 #pragma clang fp contract(off)   // mul, then add, like the reference's two tensor ops: the renderer's z-test sees these bits
@@ -233,6 +273,16 @@ int romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream) {
     ROMP_REQUIRE(x6 && aa && n >= 0, "romp_rot6d_to_aa: bad arguments");
     if (n == 0) return ROMP_OK;
     hipLaunchKernelGGL(rot6d_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, x6, n, aa);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+int romp_estimate_translation(const float* joints, int N, int J, int K, const float* pj2d, float focal_length, float img_size,
+                              float* trans, void* stream) {
+    ROMP_REQUIRE(joints && pj2d && trans && N >= 0 && J > 0 && K >= 2 && K <= J, "romp_estimate_translation: bad arguments");
+    if (N == 0) return ROMP_OK;
+    hipLaunchKernelGGL(translation_lsq_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, joints, J, K, pj2d, (double)focal_length,
+                       (double)img_size / 2.0, (double)img_size / 2.0, trans);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

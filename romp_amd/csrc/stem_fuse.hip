@@ -322,4 +322,76 @@ int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H,
     return ROMP_OK;
 }
 
+// ---- split-K tail ------------------------------------------------------------------------------------------------
+// A layer with few pixels and many input channels (16x16x256 at batch 1) gives the conv kernels a handful of work items with a
+// long serial channel loop.  The single-image plans run it as a grouped conv over G input-channel slices (G times the items,
+// 1/G of the loop) into G float32 partial tensors; this kernel adds them in slice order and applies the layer's epilogue.
+struct KsumParams {
+    const float* part; const float* res; const float* scale; const float* shift; float* out;
+    int G, C, C8, part_cs, res_cs, res_co, out_cs, out_co, relu, res_h2, out_h2;
+    float act_scale, inv_act_scale; size_t total;
+};
+
+__global__ __launch_bounds__(256) void ksum_kernel(KsumParams p) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % p.C8) * 8;
+        const size_t pix = i / p.C8;
+        const float* pp = p.part + pix * p.part_cs + c;
+        float4 va = ldg4(pp), vb = ldg4(pp + 4);
+        for (int g = 1; g < p.G; ++g) {
+            const float4 ta = ldg4(pp + (size_t)g * p.C), tb = ldg4(pp + (size_t)g * p.C + 4);
+            va.x += ta.x; va.y += ta.y; va.z += ta.z; va.w += ta.w;
+            vb.x += tb.x; vb.y += tb.y; vb.z += tb.z; vb.w += tb.w;
+        }
+        const float4 sa = ldg4(p.scale + c), sb = ldg4(p.scale + c + 4), ha = ldg4(p.shift + c), hb = ldg4(p.shift + c + 4);
+        va = make_float4(fmaf(va.x, sa.x, ha.x), fmaf(va.y, sa.y, ha.y), fmaf(va.z, sa.z, ha.z), fmaf(va.w, sa.w, ha.w));
+        vb = make_float4(fmaf(vb.x, sb.x, hb.x), fmaf(vb.y, sb.y, hb.y), fmaf(vb.z, sb.z, hb.z), fmaf(vb.w, sb.w, hb.w));
+        if (p.res) {
+            const float* rp = p.res + pix * p.res_cs + p.res_co + c;
+            const float4 u0 = ldg4(rp), u1 = ldg4(rp + 4);
+            float4 ra = u0, rb = u1;
+            if (p.res_h2) {
+                const uint4 hi = __builtin_bit_cast(uint4, u0), lo = __builtin_bit_cast(uint4, u1);
+                ra = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), p.inv_act_scale);
+                rb = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), p.inv_act_scale);
+            }
+            va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
+            vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
+        }
+        if (p.relu) {
+            va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+            vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+        }
+        float* op_ = p.out + pix * p.out_cs + p.out_co + c;
+        if (p.out_h2) {
+            uint2 h0, l0, h1, l1;
+            h2_pack(va, p.act_scale, h0, l0);
+            h2_pack(vb, p.act_scale, h1, l1);
+            *reinterpret_cast<uint4*>(op_) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(op_ + 4) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {
+            *reinterpret_cast<float4*>(op_) = va;
+            *reinterpret_cast<float4*>(op_ + 4) = vb;
+        }
+    }
+}
+
+int launch_ksum(const romp_op& op, const float* partial, const float* res, float* out, int B, hipStream_t st) {
+    ROMP_REQUIRE(partial && out && op.scale && op.shift, "ksum: null buffer");
+    ROMP_REQUIRE(op.groups >= 1 && (op.Cout & 7) == 0 && op.in_cstride == op.groups * op.Cout, "ksum: partials must be %d x %d channels", op.groups, op.Cout);
+    ROMP_REQUIRE(((op.out_cstride | op.out_coff) & 7) == 0 && (!res || ((op.res_cstride | op.res_coff) & 7) == 0), "ksum: channels must come in octets");
+    KsumParams p;
+    p.part = partial; p.res = res; p.scale = (const float*)op.scale; p.shift = (const float*)op.shift; p.out = out;
+    p.G = op.groups; p.C = op.Cout; p.C8 = op.Cout / 8; p.part_cs = op.in_cstride;
+    p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.out_cs = op.out_cstride; p.out_co = op.out_coff; p.relu = op.relu;
+    p.res_h2 = op.res_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2;
+    p.act_scale = ldexpf(1.f, op.act_shift); p.inv_act_scale = ldexpf(1.f, -op.act_shift);
+    p.total = (size_t)B * op.H * op.W * p.C8;
+    size_t blocks = (p.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ksum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
 }  // namespace romp

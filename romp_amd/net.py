@@ -15,10 +15,13 @@ from .plan import Program, build_romp_hrnet32, coord_channels, decode_h2, encode
 
 class RompNet:
     def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
-                 out_shapes=None, bf16x3=False):
+                 out_shapes=None, bf16x3=False, split_k=None):
         """`builder(state_dict, device, input_size, bf16x3=) -> Program` (default: ROMP HRNet-32 + head);
         `out_shapes`: per-image shapes of the two output tensors of the program.  `bf16x3` is the conv_math
-        setting: False / 'f32', True / 'bf16x3', 'f16x2' or 'all' (plan.set_conv_math)."""
+        setting: False / 'f32', True / 'bf16x3', 'f16x2' or 'all' (plan.set_conv_math).  `split_k`: lower the layers with few
+        pixels and many input channels as split-K convs (plan.Program.conv); default: only for single-image nets
+        (max_batch <= 2), where those layers are a handful of work items with a long serial channel loop; an int sets the
+        work-item target (default 128)."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
@@ -29,10 +32,12 @@ class RompNet:
         self.split = 1
         self.input_size = input_size
         with torch.cuda.device(self.device):
+            self.split_k = (128 if self.max_batch <= 2 else 0) if split_k is None else (128 if split_k is True else int(split_k))
+            kw = dict(split_k_items=self.split_k) if self.split_k else {}
             if builder is None:
-                self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size, bf16x3=bf16x3)
+                self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size, bf16x3=bf16x3, **kw)
             else:
-                self.program = builder(state_dict, self.device, input_size, bf16x3=bf16x3)
+                self.program = builder(state_dict, self.device, input_size, bf16x3=bf16x3, **kw)
             ops = self.program.op_array()
             sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
             h = C.c_void_p()

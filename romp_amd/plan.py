@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
-                  OP_FUSESUM, OP_JOIN, OP_STEM, RompOp)
+                  OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
 HEAD_IN_CH = 40          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 8
@@ -205,6 +205,15 @@ def assign_formats(P):
             g = gen_for_write(op.out_buf)
             g['uses'].append((i, 'out'))
             g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
+        elif op.kind == OP_KSUM:                             # float32 partial sums in, either format for the residual and the result
+            gen_for_read(op.in_buf)['ok'] = False
+            if op.res_buf >= 0:
+                g = gen_for_read(op.res_buf)
+                g['uses'].append((i, 'res'))
+                g['ok'] &= oct_ok(op.res_cstride, op.res_coff)
+            g = gen_for_write(op.out_buf)
+            g['uses'].append((i, 'out'))
+            g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
         elif op.kind in (OP_FORK, OP_JOIN):
             continue
         else:                                                # any other op: its tensors stay float32
@@ -254,6 +263,7 @@ class Program:
         self.buf_fmt: Dict[int, int] = {}                      # filled by assign_formats
         self.head_in_buf: Optional[int] = None
         self.head_in_ch, self.coord_off = HEAD_IN_CH, None     # coord_off: first of the two constant CoordConv channels
+        self.split_k_items = 0                                 # > 0 (single-image plans): split a conv's input channels until it has this many work items
 
     # ---- buffers -------------------------------------------------------------------------
     def alloc(self, floats, persistent=False):
@@ -317,9 +327,56 @@ class Program:
         return t
 
     # ---- ops -----------------------------------------------------------------------------
+    def split_k_groups(self, cin, cout, ksize, stride, Ho, Wo):
+        """Input-channel slices for a conv of a single-image plan: the smallest-tile kernels give ceil(Ho/8) * (Wo/16) *
+        ceil(cout/32) work items with a serial loop over cin; slices of >= 32 channels multiply the items (csrc/stem_fuse.hip
+        ksum_kernel adds the partial sums)."""
+        if self.split_k_items <= 0 or ksize not in (1, 3) or Wo % 16 or cout % 8:
+            return 1
+        items = -(-Ho // 8) * (Wo // 16) * -(-cout // 32)
+        g = 1
+        while items * g < self.split_k_items and cin % (2 * g) == 0 and cin // (2 * g) >= 32 and (cin // (2 * g)) % 16 == 0:
+            g *= 2
+        return g
+
     def conv(self, name, x: Act, w, scale, shift, ksize, stride, relu, res: Optional[Act] = None,
              out: Optional[Act] = None, groups=1, out_buf_special=None, out_cstride=None, out_coff=0,
              pad=(-1, -1), out_rstride=0, out_bstride=0):
+        """One conv layer; in a single-image plan (split_k_items) a layer with few pixels and many input channels becomes a
+        grouped conv over input-channel slices writing float32 partial sums + a ksum op with the layer's epilogue."""
+        G = 1
+        if groups == 1 and out_buf_special is None and not out_rstride and not out_bstride and tuple(pad) == (-1, -1) and x.coff % 8 == 0:
+            cout, cin = w[0].shape[0], w[0].shape[1]
+            if cin == x.C and x.cstride == x.C:
+                Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
+                G = self.split_k_groups(cin, cout, ksize, stride, Ho, (x.W + 2 * (ksize // 2) - ksize) // stride + 1)
+        if G == 1:
+            return self._conv_op(name, x, w, scale, shift, ksize, stride, relu, res, out, groups, out_buf_special, out_cstride,
+                                 out_coff, pad, out_rstride, out_bstride)
+        cg = cin // G
+        part = self._conv_op(name + '.splitk', x, [w[0][:, g * cg:(g + 1) * cg].contiguous() for g in range(G)],
+                             [torch.ones(cout)] * G, [torch.zeros(cout)] * G, ksize, stride, False, groups=G)
+        if out is None:
+            out = self.new_act(cout, part.H, part.W)
+        op = RompOp()
+        op.kind, op.in_buf, op.out_buf, op.res_buf = OP_KSUM, part.buf, out.buf, (res.buf if res is not None else BUF_NONE)
+        op.H, op.W, op.Cin, op.Cout, op.groups, op.relu = part.H, part.W, G * cout, cout, G, int(relu)
+        op.in_cstride, op.out_cstride, op.out_coff = part.cstride, out.cstride, out.coff
+        if res is not None:
+            op.res_cstride, op.res_coff = res.cstride, res.coff
+        ps, pb = self._dev(scale[0].float()), self._dev(shift[0].float())
+        op.scale, op.shift = ps.data_ptr(), pb.data_ptr()
+        op.stream = self.cur_stream
+        self.ops.append(op)
+        self.names.append(name + '.ksum')
+        self.flops.append(float(part.H * part.W * cout * (G + 1)))
+        self.bytes.append(4.0 * part.H * part.W * cout * (G + 1 + (1 if res is not None else 0)))
+        self.free(part)
+        return out
+
+    def _conv_op(self, name, x: Act, w, scale, shift, ksize, stride, relu, res: Optional[Act] = None,
+                 out: Optional[Act] = None, groups=1, out_buf_special=None, out_cstride=None, out_coff=0,
+                 pad=(-1, -1), out_rstride=0, out_bstride=0):
         """w: list (per group) of OIHW tensors; scale/shift: list of per-group vectors.  pad: zero rows / columns
         before the first tap (-1: ksize//2); out_rstride / out_bstride: sparse output row / image strides (floats) for
         the interleaved parity outputs of a transposed conv (`out` then is the full-resolution tensor)."""
@@ -534,10 +591,12 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
     return head_in
 
 
-def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512, bf16x3=False) -> Program:
-    """state_dict of ROMPv1 (model.py:420-481) -> Program.  `bf16x3`: the conv_math setting (see set_conv_math)."""
+def build_romp_hrnet32(sd: Dict[str, torch.Tensor], device, input_size=512, bf16x3=False, split_k_items=0) -> Program:
+    """state_dict of ROMPv1 (model.py:420-481) -> Program.  `bf16x3`: the conv_math setting (see set_conv_math);
+    `split_k_items` > 0: single-image plan (Program.conv)."""
     sd = _clean(sd)
     P = Program(device)
+    P.split_k_items = split_k_items
     set_conv_math(P, bf16x3)
     # backbone output lands in 32 of the 40 channels of the head input buffer; channels 32,33 hold the
     # constant CoordConv maps (model.py:473), 34..39 are zero padding.

@@ -46,15 +46,16 @@ def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person):
     pm = params_maps_nhwc.contiguous()
     assert pm.shape == (B, 64, 64, 145) and pm.dtype == torch.float32
     cap = B * max_person
-    i32 = dict(device=dev, dtype=torch.int32)
-    f32 = dict(device=dev, dtype=torch.float32)
-    out = {
-        'batch_ids': torch.empty(cap, **i32), 'flat_inds': torch.empty(cap, **i32),
-        'scores': torch.empty(cap, **f32), 'params_pred': torch.empty(cap, 145, **f32),
-        'cam': torch.empty(cap, 3, **f32), 'smpl_thetas': torch.empty(cap, 72, **f32),
-        'smpl_betas': torch.empty(cap, 10, **f32), 'center_preds': torch.empty(cap, 2, **i32),
-    }
-    ws = torch.empty(B * (2 * max_person + 2), **i32)
+    # one allocation per dtype, sliced: the single-image path pays for every torch.empty
+    ibuf = torch.empty(cap * 4 + B * (2 * max_person + 2), device=dev, dtype=torch.int32)
+    fbuf = torch.empty(cap * (1 + 145 + 3 + 72 + 10), device=dev, dtype=torch.float32)
+    out, at = {}, 0
+    for key, w in (('scores', 1), ('params_pred', 145), ('cam', 3), ('smpl_thetas', 72), ('smpl_betas', 10)):
+        out[key] = fbuf[at:at + cap * w].view(cap, w) if w > 1 else fbuf[at:at + cap]
+        at += cap * w
+    out['batch_ids'], out['flat_inds'] = ibuf[:cap], ibuf[cap:2 * cap]
+    out['center_preds'] = ibuf[2 * cap:4 * cap].view(cap, 2)
+    ws = ibuf[4 * cap:]
     n = C.c_int32(0)
     with torch.cuda.device(dev):
         L.check(lib.romp_parse(L.ptr(cm), L.ptr(pm), B, float(conf_thresh), int(max_person), C.byref(n),
@@ -65,9 +66,8 @@ def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person):
     if N == 0:
         return None
     out = {k: v[:N] for k, v in out.items()}
-    out['batch_ids'] = out['batch_ids'].long()
-    out['flat_inds'] = out['flat_inds'].long()
-    out['center_preds'] = out['center_preds'].long()
+    il = ibuf[:4 * cap].long()                                # the reference's index tensors are int64: one cast for the three
+    out['batch_ids'], out['flat_inds'], out['center_preds'] = il[:N], il[cap:cap + N], il[2 * cap:4 * cap].view(cap, 2)[:N]
     return out
 
 
@@ -108,38 +108,45 @@ def convert_cam_to_3d_trans(cams, weight=2.):
     return torch.stack([tx / s, ty / s, 1. / s], 1) * weight
 
 
+try:
+    import cv2 as _cv2  # noqa: F401
+    _HAVE_CV2 = True
+except Exception:
+    _HAVE_CV2 = False
+
+
 def estimate_translation_lsq(joints_3d, joints_2d, focal_length=443.4, img_size=(512., 512.)):
-    """Camera translation by linear least squares -- the reference's non-OpenCV branch
-    (estimate_translation_np, utils.py:350-389; taken when cv2.solvePnPRansac is unavailable,
-    utils.py:429-434).  joints_3d (N,K,3), joints_2d (N,K,2) numpy.  Host-side, O(N*K)."""
+    """Camera translation by linear least squares -- the reference's estimate_translation without OpenCV (utils.py:391-434 ->
+    estimate_translation_np :347-389): host statement of csrc/parse.hip translation_lsq_kernel.  A joint counts when its
+    pixel row coordinate is > -2 (the reference's `joints_2d[:, :, -1] > -2.`); fewer than 4 -> (-1,-1,-1).
+    joints_3d (N,K,3), joints_2d (N,K,2) numpy."""
     X = np.asarray(joints_3d, np.float64)
     uv = np.asarray(joints_2d, np.float64)
-    N, K = X.shape[:2]
+    N = X.shape[0]
     f = float(focal_length)
     c = np.asarray(img_size, np.float64) / 2.
-    Q = np.zeros((N, 2 * K, 3))
-    Q[:, 0::2, 0] = f
-    Q[:, 1::2, 1] = f
-    Q[:, 0::2, 2] = c[0] - uv[:, :, 0]
-    Q[:, 1::2, 2] = c[1] - uv[:, :, 1]
-    rhs = np.zeros((N, 2 * K))
-    rhs[:, 0::2] = (uv[:, :, 0] - c[0]) * X[:, :, 2] - f * X[:, :, 0]
-    rhs[:, 1::2] = (uv[:, :, 1] - c[1]) * X[:, :, 2] - f * X[:, :, 1]
-    A = np.einsum('nki,nkj->nij', Q, Q)
-    b = np.einsum('nki,nk->ni', Q, rhs)
+    w = ((np.asarray(joints_2d)[:, :, -1] > -2.) & (np.asarray(joints_3d)[:, :, -1] != -2.)).astype(np.float64)
+    qx, qy = (c[0] - uv[:, :, 0]) * w, (c[1] - uv[:, :, 1]) * w
+    rx = ((uv[:, :, 0] - c[0]) * X[:, :, 2] - f * X[:, :, 0]) * w
+    ry = ((uv[:, :, 1] - c[1]) * X[:, :, 2] - f * X[:, :, 1]) * w
     out = np.full((N, 3), -1.0, np.float32)
     for i in range(N):
-        try:
-            out[i] = np.linalg.solve(A[i], b[i])
-        except np.linalg.LinAlgError:
-            pass
+        d = w[i].sum() * f * f
+        A = np.array([[d, 0, f * qx[i].sum()], [0, d, f * qy[i].sum()], [f * qx[i].sum(), f * qy[i].sum(), (qx[i] ** 2 + qy[i] ** 2).sum()]])
+        b = np.array([f * rx[i].sum(), f * ry[i].sum(), (qx[i] * rx[i] + qy[i] * ry[i]).sum()])
+        if w[i].sum() >= 4:
+            try:
+                out[i] = np.linalg.solve(A, b)
+            except np.linalg.LinAlgError:
+                pass
     return out
 
 
 def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_offsets=None):
     """post_parser.py:104-114.  pj2d / pj2d_org on device (csrc/parse.hip project_kernel);
-    `cam_trans` follows the reference's PnP step on the host (cv2.solvePnPRansac when OpenCV is
-    installed, else the reference's own least-squares fallback) -- a non-gated output."""
+    `cam_trans` follows the reference's PnP step (post_parser.py:96-101): cv2.solvePnPRansac on the host when OpenCV is
+    installed, else the reference's own least-squares fallback (utils.py:347-389) on the device
+    (csrc/parse.hip translation_lsq_kernel; `estimate_translation_lsq` below is its host statement)."""
     lib = L.load()
     dev = j3d_preds.device
     j = j3d_preds.contiguous().float()
@@ -153,22 +160,28 @@ def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_of
     with torch.cuda.device(dev):
         L.check(lib.romp_project(L.ptr(j), N, J, L.ptr(cam), pad_c, L.ptr(pj2d), L.ptr(pj2d_org), L.ptr(ct),
                                  L.stream_ptr(dev)))
-    j24 = j[:, :24].detach().cpu().numpy()
-    p24 = (pj2d[:, :24].detach().cpu().numpy() + 1) * 256            # post_parser.py:98
     trans = None
-    try:
+    if _HAVE_CV2:                                                      # the reference's first choice: OpenCV PnP on the host
         import cv2
+        j24 = j[:, :24].detach().cpu().numpy()
+        p24 = (pj2d[:, :24].detach().cpu().numpy() + 1) * 256        # post_parser.py:98
         camK = np.eye(3)
         camK[0, 0] = camK[1, 1] = 443.4
         camK[:2, 2] = 256
-        trans = np.zeros((N, 3), np.float32)
-        for i in range(N):
-            ret, rvec, tvec, inl = cv2.solvePnPRansac(j24[i], p24[i], camK, None, flags=cv2.SOLVEPNP_EPNP,
-                                                      reprojectionError=20, iterationsCount=100)
-            trans[i] = -1 if inl is None else tvec[:, 0]
-    except Exception:
-        trans = estimate_translation_lsq(j24, p24)
-    out = {'pj2d': pj2d, 'cam_trans': torch.from_numpy(trans).float().to(dev)}
+        try:
+            t = np.zeros((N, 3), np.float32)
+            for i in range(N):
+                ret, rvec, tvec, inl = cv2.solvePnPRansac(j24[i], p24[i], camK, None, flags=cv2.SOLVEPNP_EPNP,
+                                                          reprojectionError=20, iterationsCount=100)
+                t[i] = -1 if inl is None else tvec[:, 0]
+            trans = torch.from_numpy(t).float().to(dev)
+        except Exception:
+            trans = None
+    if trans is None:                                                  # its fallback, the linear least squares: on the device
+        trans = torch.empty(N, 3, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.romp_estimate_translation(L.ptr(j), N, J, 24, L.ptr(pj2d), 443.4, 512., L.ptr(trans), L.stream_ptr(dev)))
+    out = {'pj2d': pj2d, 'cam_trans': trans}
     if input2org_offsets is not None:
         out['pj2d_org'] = pj2d_org
     if vertices is not None:                                           # post_parser.py:107-113 (dropped again before return unless rendering)

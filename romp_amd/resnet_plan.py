@@ -48,9 +48,10 @@ def _maxpool(P: Program, name, x: Act):
     return out
 
 
-def build_romp_resnet50(sd, device, input_size=512, bf16x3=False) -> Program:
+def build_romp_resnet50(sd, device, input_size=512, bf16x3=False, split_k_items=0) -> Program:
     sd = _clean(sd)
     P = Program(device)
+    P.split_k_items = split_k_items                           # > 0: single-image plan (plan.Program.conv)
     set_conv_math(P, bf16x3)
     bb = 'backbone.'
 

@@ -79,13 +79,28 @@ def img_preprocess_device(image, device, input_size=512):
 
 
 def convert_tensor2numpy(outputs, del_keys=('verts_camed', 'smpl_face', 'pj2d', 'verts_camed_org')):
-    """utils.py:32-41."""
+    """utils.py:32-41.  The device tensors of one dtype travel in ONE device-to-host copy (a dozen small `.cpu()` calls cost
+    more than the single-image network's post-processing); the arrays returned are views of that host block."""
     for key in del_keys:
         if key in outputs:
             del outputs[key]
-    for key in list(outputs.keys()):
-        if isinstance(outputs[key], torch.Tensor):
-            outputs[key] = outputs[key].cpu().numpy()
+    groups = {}
+    for key, v in outputs.items():
+        if isinstance(v, torch.Tensor):
+            if v.is_cuda:
+                groups.setdefault((v.dtype, v.device), []).append(key)
+            else:
+                outputs[key] = v.numpy()
+    for (dtype, device), keys in groups.items():
+        if len(keys) == 1:
+            outputs[keys[0]] = outputs[keys[0]].cpu().numpy()
+            continue
+        flat = torch.cat([outputs[k].reshape(-1) for k in keys]).cpu().numpy()
+        at = 0
+        for k in keys:
+            n = outputs[k].numel()
+            outputs[k] = flat[at:at + n].reshape(tuple(outputs[k].shape))
+            at += n
     return outputs
 
 

@@ -28,3 +28,23 @@ with torch.cuda.stream(st):
     torch.cuda.synchronize(); dn = (time.perf_counter() - t0) / n
 print('ROMP(image) 720p frame, %d persons: %.2f ms = %.0f FPS end to end (upload + preprocess + net + parse + SMPL + projection + download); network alone B=1: %.2f ms'
       % (0 if out is None else out['cam'].shape[0], dt * 1e3, 1 / dt, dn * 1e3))
+
+# ---- stage breakdown (synchronised between stages: slower in total than the pipelined call above)
+from romp_amd.utils import img_preprocess_device, convert_tensor2numpy
+from romp_amd.post_parser import parsing_outputs
+import collections
+acc = collections.OrderedDict()
+def tick(name, t0):
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    acc[name] = acc.get(name, 0.) + (t1 - t0)
+    return t1
+with torch.cuda.stream(st):
+    for it in range(30):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        x, pad = img_preprocess_device(frame, model.tdevice); t = tick('upload + preprocess', t)
+        cm, pm = model.model(x); t = tick('network', t)
+        o = parsing_outputs(cm, pm, model.centermap_parser); t = tick('parse', t)
+        o = model._finish(o, pad); t = tick('SMPL + projection (+ host PnP)', t)
+        o = convert_tensor2numpy(o); t = tick('download', t)
+print('stages (ms, synchronised): ' + ', '.join('%s %.3f' % (k, v / 30 * 1e3) for k, v in acc.items()))

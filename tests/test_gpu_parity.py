@@ -372,6 +372,55 @@ def test_net_bf16x3_parity(dev, golden_dir, conv_math):
     assert ec < 1e-4 and ep < 1e-4
 
 
+def test_translation_lsq_vs_reference_fixture(dev, golden_dir):
+    """romp_estimate_translation (the cam_trans of body_mesh_projection2image when OpenCV is absent) against the
+    reference's estimate_translation recorded with cv2 absent (oracle/make_golden_translation.py)."""
+    from romp_amd import lib as L
+    g = _g(golden_dir, 'translation_lsq.npz')
+    lib = L.load()
+    j, pj = torch.from_numpy(g['joints']).to(dev).contiguous(), torch.from_numpy(g['pj2d']).to(dev).contiguous()
+    N = j.shape[0]
+    out = torch.empty(N, 3, device=dev)
+    L.check(lib.romp_estimate_translation(L.ptr(j), N, 71, 24, L.ptr(pj), 443.4, 512., L.ptr(out), L.stream_ptr(dev)))
+    err = np.abs(out.cpu().numpy() - g['trans']).max()
+    print('device least-squares translation vs reference: max-abs %.3e' % err)
+    np.testing.assert_allclose(out.cpu().numpy(), g['trans'], rtol=2e-5, atol=2e-6)
+    # through the post-processing entry point
+    from romp_amd.post_parser import body_mesh_projection2image, _HAVE_CV2
+    if not _HAVE_CV2:
+        r = body_mesh_projection2image(j, torch.from_numpy(g['cam']).to(dev))
+        np.testing.assert_allclose(r['cam_trans'].cpu().numpy(), g['trans'], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r['pj2d'].cpu().numpy(), g['pj2d'], atol=1e-6)
+
+
+@pytest.mark.parametrize('conv_math', ['f32', 'f16x2'])
+def test_net_split_k_single_image(dev, golden_dir, conv_math):
+    """Single-image nets (max_batch <= 2) lower the layers with few pixels and many input channels as split-K convs (grouped
+    conv over input-channel slices -> float32 partials -> ksum with the layer's epilogue).  Same gates as every other plan:
+    1e-4 against the reference fixture (B=1) and the oracle (B=2); and the plan really contains the split layers."""
+    from romp_amd.net import RompNet
+    from romp_amd.lib import OP_KSUM
+    sd = O.make_romp_state_dict(0)
+    net = RompNet(sd, dev, max_batch=2, bf16x3=conv_math)
+    n_ksum = sum(o.kind == OP_KSUM for o in net.program.ops)
+    assert net.split_k == 128 and n_ksum > 50
+    g = _g(golden_dir, 'romp_net_b1.npz')
+    cm, pm = net(O.make_images(1, seed=1).to(dev))
+    p = pm[0].reshape(145, -1).cpu().numpy()
+    ec = np.abs(cm.cpu().numpy() - g['center_maps']).max()
+    ep = np.abs(p[:, g['sample_pos']] - g['params_samples']).max()
+    print(f'split-K {conv_math} ({n_ksum} split layers) B=1 vs reference fixture: center {ec:.3e} params {ep:.3e}')
+    assert ec < 1e-4 and ep < 1e-4
+    img = O.make_images(2, seed=5)
+    cm_o, pm_o = O.romp_net_forward(sd, img)
+    cm, pm = net(img.to(dev))
+    ec, ep = (cm.cpu() - cm_o).abs().max().item(), (pm.cpu() - pm_o).abs().max().item()
+    print(f'split-K {conv_math} B=2 vs oracle: center {ec:.3e} params {ep:.3e}')
+    assert ec < 1e-4 and ep < 1e-4
+    # the default plan of a larger net has none
+    assert RompNet(sd, dev, max_batch=4).split_k == 0
+
+
 def test_net_batch_lanes(dev):
     """set_split(2): the forward runs as two half-batch lanes on two streams (convs capped at one
     workgroup per CU).  Same maps as the oracle for every image of the batch, eagerly and from a hipGraph;
