@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle comparison of the timed batch')
     ap.add_argument('--no-end-to-end', action='store_true', help='skip the uint8-host-frames (H2D + pre-processing) timing')
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the extra conv_math=f32 timing of the same workload')
+    ap.add_argument('--no-latency', action='store_true', help='skip the single-image ROMP(settings)(frame) latency leg')
     ap.add_argument('--with-verts', type=int, default=0, help='N>1: also all-gather the 6890x3 vertices')
     return ap.parse_args()
 
@@ -274,6 +275,41 @@ def end_to_end(model, lib, L, dev, batch, n_calls, stream):
     return dict(value=round(batch * n_calls / dt, 2), unit='images/s', ms_per_call=round(dt / n_calls * 1e3, 3), calls=n_calls,
                 includes='per call: H2D of %d uint8 512x512x3 frames from pinned host memory + device pre-processing + net + parse + SMPL '
                          '(one stream, no copy/compute overlap)' % batch)
+
+
+def single_image_latency(sd, smpl_model, args, dev, stream, n=40):
+    """The reference's only published speed is one image at a time (docs/romp_evaluation.md:96-102: 23.8 FPS on a GTX 1070Ti):
+    `romp.ROMP(settings)(bgr_frame)` on a 720p frame -- upload + device pre-processing + single-image network plan (split-K
+    lowering, hipGraph) + parse + SMPL + projection + download of the result dict -- and the network alone at B = 1."""
+    import numpy as np
+    import romp_amd
+    from romp_amd import synthetic as S
+    s = romp_amd.romp_settings([])
+    s.GPU, s.center_thresh, s.max_batch, s.conv_math = dev.index or 0, args.center_thresh, 1, args.conv_math
+    m = romp_amd.ROMP(s, state_dict=sd, smpl_model=smpl_model)
+    m.model.set_graph(True)
+    frame = np.random.RandomState(0).randint(0, 256, (720, 1280, 3)).astype(np.uint8)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            out = m(frame)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = m(frame)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n
+        x = S.make_images(1, seed=1, device=dev)
+        c, p = m.model.forward_nhwc(x)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m.model.forward_nhwc(x, c, p)
+        torch.cuda.synchronize(dev)
+        dn = (time.perf_counter() - t0) / n
+    return {'fps': round(1.0 / dt, 1), 'ms_per_frame': round(dt * 1e3, 3), 'network_ms': round(dn * 1e3, 3), 'frame': '1280x720 uint8 BGR from host memory',
+            'persons': 0 if out is None else int(out['cam'].shape[0]), 'calls': n,
+            'includes': 'romp.ROMP(settings)(frame): H2D + pad/resize + network (single-image plan: %d ops, split-K) + parse + SMPL + projection + D2H of the result dict'
+                        % len(m.model.program.ops)}
 
 
 # ------------------------------------------------------------------------------------------------ other workloads
@@ -555,6 +591,8 @@ def main():
                                             'ms_per_step': round(dt32 / k32 * 1e3, 3),
                                             'note': 'same job, conv_math=f32 (v_mfma_f32_32x32x2_f32 only)'}
             del m32
+        if world == 1 and args.backbone == 'hrnet32' and not args.no_latency:
+            result['single_image_latency'] = single_image_latency(sd, smpl_model, args, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(sd, smpl_model, args.center_thresh, args.cpu_seconds)
         print(json.dumps(result), flush=True)

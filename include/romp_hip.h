@@ -231,6 +231,9 @@ void smpl_ctx_destroy(smpl_ctx* ctx);
 int  romp_project(const float* joints, int N, int J, const float* cam, const float* pad_info_host,
                   float* pj2d, float* pj2d_org, float* cam_trans, void* stream);
 
+/* convert_cam_to_3d_trans (utils.py:303-307): cam (N,3) = (s, tx, ty) -> trans (N,3) = (tx/s, ty/s, 1/s) * weight. */
+int  romp_cam_to_trans(const float* cam, int N, float weight, float* trans, void* stream);
+
 /* convert_cam_to_3d_trans2 (post_parser.py:96-101) with the reference's linear least-squares estimator
  * (estimate_translation_np, utils.py:347-389: its path when OpenCV's PnP is not available): joints (N,J,3), the first K
  * of them against their normalised orthographic projections pj2d (N,J,2) mapped to (pj2d + 1) * img_size / 2 pixels

@@ -42,6 +42,7 @@ struct romp_net {
     int max_batch = 0;
     int mode = 0;
     int use_graph = 0;
+    int first_op = 0;                    // run_lane starts here (graph replay: the stem, the only reader of the caller's image, runs eagerly)
     int use_streams = 1;                 // run FORK/JOIN regions on side streams
     // Batch lanes: with split == 2 a forward of B images runs as two independent half-batch op sequences
     // on two streams (lane 0 on the caller's stream), each conv capped at one workgroup per CU, so the
@@ -194,7 +195,7 @@ static int run_lane(romp_net* n, const float* image, int B, float* center, float
     const std::vector<int>* tv = tuned_for(n, B);
     const bool ms = n->use_streams && n->mode == 0;
     int convs_seen = 0;
-    for (size_t i = 0; i < n->ops.size(); ++i) {
+    for (size_t i = (size_t)n->first_op; i < n->ops.size(); ++i) {
         const romp_op& op = n->ops[i];
         if (op.kind == ROMP_OP_FORK) {
             if (!ms) continue;
@@ -332,7 +333,11 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     hipStream_t st = (hipStream_t)stream;
     if (!n->use_graph || n->mode != 0) return run_all(n, image, B, center, params, st);
     ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
-    if (n->graphs.size() >= 32 && !n->graphs.count(GraphKey{B, image, center, params, lanes_active(n, B) ? 0 : -1})) {
+    // The stem is the only op that reads the caller's image: launched eagerly in front of the graph, the graph no longer
+    // depends on WHERE the input lives (a caller streaming frames from ever new tensors replays one graph).
+    const bool stem_out = !lanes_active(n, B) && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
+    const float* key_image = stem_out ? nullptr : image;
+    if (n->graphs.size() >= 32 && !n->graphs.count(GraphKey{B, key_image, center, params, lanes_active(n, B) ? 0 : -1})) {
         // a caller that hands over new tensors every call must not grow the cache for ever
         ROMP_HIP_CHECK(hipStreamSynchronize(st));
         ROMP_HIP_CHECK(hipStreamSynchronize(n->lane_main));
@@ -353,8 +358,14 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
         return ROMP_OK;
     };
     if (!lanes_active(n, B)) {
-        const GraphKey key{B, image, center, params, -1};
+        const GraphKey key{B, key_image, center, params, -1};
+        if (stem_out) {
+            const int rc0 = run_op(n, 0, -1, image, B, center, params, st);
+            if (rc0) return rc0;
+        }
+        n->first_op = stem_out ? 1 : 0;
         const int rc = capture(st, key, [&] { return run_all(n, image, B, center, params, st); });
+        n->first_op = 0;
         if (rc) return rc;
         ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[key], st));
         return ROMP_OK;

@@ -149,6 +149,16 @@ __global__ void project_kernel(const float* __restrict__ joints, int N, int J, c
     }
 }
 
+// convert_cam_to_3d_trans (utils.py:303-307): (s, tx, ty) -> (tx / s, ty / s, 1 / s) * weight
+__global__ void cam_to_trans_kernel(const float* __restrict__ cam, int N, float weight, float* __restrict__ trans) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float s = cam[i * 3], tx = cam[i * 3 + 1], ty = cam[i * 3 + 2];
+    trans[i * 3 + 0] = (tx / s) * weight;
+    trans[i * 3 + 1] = (ty / s) * weight;
+    trans[i * 3 + 2] = (1.f / s) * weight;
+}
+
 // Camera translation that best explains the orthographic projection under the perspective camera: the reference's
 // estimate_translation with OpenCV absent (utils.py:391-434 -> estimate_translation_np :347-389, unit weights) over the
 // first K joints.  A joint counts when its pixel ROW coordinate is > -2 (`joints_conf = joints_2d[:, :, -1] > -2.`, :405-406,
@@ -273,6 +283,14 @@ int romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream) {
     ROMP_REQUIRE(x6 && aa && n >= 0, "romp_rot6d_to_aa: bad arguments");
     if (n == 0) return ROMP_OK;
     hipLaunchKernelGGL(rot6d_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, x6, n, aa);
+    ROMP_HIP_CHECK(hipGetLastError());
+    return ROMP_OK;
+}
+
+int romp_cam_to_trans(const float* cam, int N, float weight, float* trans, void* stream) {
+    ROMP_REQUIRE(cam && trans && N >= 0, "romp_cam_to_trans: bad arguments");
+    if (N == 0) return ROMP_OK;
+    hipLaunchKernelGGL(cam_to_trans_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, cam, N, weight, trans);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

@@ -103,9 +103,12 @@ def rot6D_to_angular(rot6D):
 
 
 def convert_cam_to_3d_trans(cams, weight=2.):
-    """utils.py:303-307 (kept as the reference's three-op torch expression; O(N) plumbing)."""
-    s, tx, ty = cams[:, 0], cams[:, 1], cams[:, 2]
-    return torch.stack([tx / s, ty / s, 1. / s], 1) * weight
+    """utils.py:303-307 (one kernel, csrc/parse.hip cam_to_trans_kernel)."""
+    cams = cams.contiguous().float()
+    out = torch.empty(cams.shape[0], 3, device=cams.device)
+    with torch.cuda.device(cams.device):
+        L.check(L.load().romp_cam_to_trans(L.ptr(cams), cams.shape[0], float(weight), L.ptr(out), L.stream_ptr(cams.device)))
+    return out
 
 
 try:
