@@ -378,8 +378,12 @@ def bench_bev(args, dev):
     model = bev.BEV(s, state_dict=sd, smpla_model=smpla, smil_model=smil)
     images = S.make_images(args.batch, seed=4, device=dev)
     net = model.model.net
-    if args.autotune:
+    if args.tune_file and os.path.exists(args.tune_file):
+        net.set_tuned(args.batch, json.load(open(args.tune_file))[str(args.batch)])
+    elif args.autotune:
         net.autotune(args.batch)
+        if args.tune_file:
+            json.dump({str(args.batch): net.tuned_variants(args.batch)}, open(args.tune_file, 'w'))
     pads = torch.tensor([[0., 512., 0., 512., 512., 512.]]).repeat(args.batch, 1)
     # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
     # ~12 persons per image, the load the ROMP line runs at

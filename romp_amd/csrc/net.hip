@@ -335,7 +335,8 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
     // The stem is the only op that reads the caller's image: launched eagerly in front of the graph, the graph no longer
     // depends on WHERE the input lives (a caller streaming frames from ever new tensors replays one graph).
-    const bool stem_out = !lanes_active(n, B) && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
+    static const bool stem_in_graph = getenv("ROMP_STEM_IN_GRAPH") != nullptr;      // A/B switch for the measurement in DESIGN.md
+    const bool stem_out = !stem_in_graph && !lanes_active(n, B) && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
     const float* key_image = stem_out ? nullptr : image;
     if (n->graphs.size() >= 32 && !n->graphs.count(GraphKey{B, key_image, center, params, lanes_active(n, B) ? 0 : -1})) {
         // a caller that hands over new tensors every call must not grow the cache for ever

@@ -103,7 +103,7 @@ class RompNet:
         c, p = self.forward_nhwc(image)
         return c.unsqueeze(1), p.permute(0, 3, 1, 2)
 
-    def autotune(self, B, iters=3):
+    def autotune(self, B, iters=5):
         """Pick the fastest conv kernel variant per layer for batch size B (measured on device)."""
         with torch.cuda.device(self.device):
             L.check(self.lib.romp_net_autotune(self._h, int(B), int(iters), L.stream_ptr(self.device)))

@@ -12,7 +12,7 @@ export PYTHONUNBUFFERED=1
 # (no autotune measuring launches); ${BENCH_ARGS} e.g. "--conv-math f32" or "--workload bev"
 TUNE=/tmp/romp_tune.json
 rm -f $TUNE
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --no-end-to-end --global-batch 64 --tune-file $TUNE ${BENCH_ARGS}"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --no-end-to-end --no-latency --global-batch 64 --tune-file $TUNE ${BENCH_ARGS}"
 $BENCH --steps 2 --warmup 1 --no-roofline > "$OUT/bench_plain.log" 2>&1
 echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
@@ -51,7 +51,20 @@ for k in sorted(agg, key=lambda k: -agg[k][counters[0]]):
     print('"%s",%d,' % (k, cnt[k]) + ','.join('%.1f' % (agg[k][c] / max(cnt[k], 1)) for c in counters))
 PY
 done
+grep '^{' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/bench_under_rocprof.json"
+grep '^{' "$OUT/bench_under_rocprof_serial.log" | tail -1 > "$OUT/bench_under_rocprof_serial.json"
+# the other workloads: kernel-trace stats only
+if [ -z "${BENCH_ARGS}" ]; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_smpl -o stats -- python $REPO/bench.py --workload smpl --no-cpu-baseline > "$OUT/bench_smpl_under_rocprof.log" 2>&1
+  find /tmp/rp_smpl -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_smpl.csv" \;
+  rm -f /tmp/romp_tune_bev.json
+  python $REPO/bench.py --workload bev --no-cpu-baseline --no-roofline --steps 2 --warmup 1 --tune-file /tmp/romp_tune_bev.json > "$OUT/bench_bev_plain.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bev -o stats -- python $REPO/bench.py --workload bev --no-cpu-baseline --steps 5 --warmup 2 --tune-file /tmp/romp_tune_bev.json > "$OUT/bench_bev_under_rocprof.log" 2>&1
+  find /tmp/rp_bev -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bev.csv" \;
+  grep '^{' "$OUT/bench_bev_under_rocprof.log" | tail -1 > "$OUT/bench_bev_under_rocprof.json"
+  head -8 "$OUT/kernel_stats_smpl.csv"; head -12 "$OUT/kernel_stats_bev.csv"
+fi
 head -14 "$OUT/kernel_stats.csv"; head -14 "$OUT/kernel_stats_serial.csv"
-tail -1 "$OUT/bench_under_rocprof.log" | cut -c1-600
+cut -c1-600 "$OUT/bench_under_rocprof.json"
 head -16 "$OUT/pmc_FETCH_SIZE_by_kernel.csv"; head -16 "$OUT/pmc_WRITE_SIZE_by_kernel.csv"
 head -12 "$OUT"/pmc_MfmaUtil*_by_kernel.csv; head -12 "$OUT"/pmc_SQ_WAVE*_by_kernel.csv
