@@ -24,6 +24,9 @@ static ConvVariant kVariantsH2[] = {
     ROMP_CONV_VARIANT_H2(1, 1, 1, 1, 16, 32), ROMP_CONV_VARIANT_H2(1, 1, 1, 1, 32, 32), ROMP_CONV_VARIANT_H2(1, 1, 2, 1, 16, 32),
     ROMP_CONV_VARIANT_H2(1, 1, 1, 1, 16, 16), ROMP_CONV_VARIANT_H2(2, 1, 1, 1, 16, 16), ROMP_CONV_VARIANT_H2(1, 2, 1, 1, 16, 32),
     ROMP_CONV_VARIANT_H2(1, 1, 4, 2, 32, 32), ROMP_CONV_VARIANT_H2(1, 1, 4, 1, 32, 32), ROMP_CONV_VARIANT_H2(1, 2, 1, 2, 16, 32),
+    // 32 input channels per stage: a 32-channel layer is ONE stage per work item (half the barriers and load-issue passes)
+    // (wider tiles at this depth spill: <3,1,1,2,16,32> 196 B, <3,1,2,1,16,32> 232 B of scratch)
+    ROMP_CONV_VARIANT_H2(3, 1, 1, 1, 16, 32),
 };
 ConvVariant* conv_variants_h2(int* n) { *n = (int)(sizeof(kVariantsH2) / sizeof(kVariantsH2[0])); return kVariantsH2; }
 
