@@ -148,10 +148,9 @@ class ROMP(nn.Module):
         from norfair import Detection
         from .utils import get_tracked_ids
         detections = [Detection(points=cam[[2, 1]] * 512) for cam in outputs['cam'].cpu().numpy()]
-        if not self.tracker_initialized:
-            for _ in range(8):
+        if not self.tracker_initialized:                  # the reference never sets the flag (main.py:141-143): the eight warm-up
+            for _ in range(8):                            # updates run on EVERY frame; kept, the track ids depend on it
                 self.tracker.update(detections=detections)
-            self.tracker_initialized = True
         tracked_objects = self.tracker.update(detections=detections)
         if len(tracked_objects) == 0:
             return outputs
