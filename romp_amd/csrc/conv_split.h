@@ -345,7 +345,9 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
         if (ch == 0 && tid == 0) j_after = atomicAdd(p.queue + q * QUEUE_STRIDE, 1) + nwg_q;
         if (pf && !(p.dbg & 1)) issue_loads(tgt, c0);
         ROMP_TRACE(10);                                // stage start: next loads issued
+        if (p.dbg & 256) __builtin_amdgcn_s_setprio(2);        // experiment: the wave in its MFMA block wins issue arbitration
         if (!(p.dbg & 8)) mma_stage_split<NP, KS, S, MT, NT, TW, CK>(sA, sB, xoff, woff, acc);
+        if (p.dbg & 256) __builtin_amdgcn_s_setprio(0);
         ROMP_TRACE(11);                                // MFMA block done
         if (ch == 0 && tid == 0) sQ[0] = j_after;
         __syncthreads();
@@ -542,6 +544,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
         if (pfA && !(p.dbg & (1 | 64))) issue_A(tgtB, c0B);
         __builtin_amdgcn_sched_barrier(0);               // keep every DMA / load issue ABOVE the MFMA block (hipcc sank 3 of the 5 DMAs below it)
         ROMP_TRACE(10);
+        if (p.dbg & 256) __builtin_amdgcn_s_setprio(2);
         if (!(p.dbg & 8)) {
             const char* sBc = sB + bbuf * (X::SUB_UNITS * 16);
 #pragma unroll
@@ -565,6 +568,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
                         for (int n = 0; n < NT; ++n) acc[m][n] = Piece<NP>::mma(wf[n], xf[m], acc[m][n]);
                 }
         }
+        if (p.dbg & 256) __builtin_amdgcn_s_setprio(0);
         ROMP_TRACE(11);
         if (ch == 0 && row == 0 && tid == 0) sQ[2 + par] = j_after;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA has landed (and ra is in)
