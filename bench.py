@@ -17,7 +17,7 @@ float32-accurate end to end (convs as f16x2-split products with f32 accumulation
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the field meanings).  After the timed region rank 0 additionally
 measures (a) the per-kernel-class roofline with HIP events on the launch stream, (b) parity of the timed batch against the
 oracle (maps, detections, meshes), (c) the same job end to end from uint8 host frames (H2D + device pre-processing inside the
-timed region) and (d) the CPU baseline (the oracle restatement of the reference, timed on the host cores of this box on a
+timed region), (d) the same job with conv_math=f32, (e) the single-image latency of the drop-in API and (f) the CPU baseline (the oracle restatement of the reference, timed on the host cores of this box on a
 bounded sample of the same workload).
 """
 import argparse

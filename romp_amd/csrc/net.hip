@@ -4,7 +4,7 @@
 // romp_op; this file owns the activation arena (NHWC float32, sized for max_batch, resident in HBM
 // for the life of the context), the per-op work queues of the persistent conv kernels, the
 // per-batch-size kernel-variant table filled by romp_net_autotune, and replays the list on the
-// caller's stream -- eagerly, or from a hipGraph captured per (batch, I/O pointers) so that the
+// caller's stream -- eagerly, or from a hipGraph captured per (batch, output pointers; the stem runs eagerly in front of it) so that the
 // ~330 dependent launches of one forward cost one graph launch on the host.
 #include "common.h"
 #include <algorithm>
