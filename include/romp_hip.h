@@ -149,6 +149,14 @@ int  romp_net_tuned_variant(romp_net* net, int B, int op_index);
 /* Install a variant table for batch B without measuring (e.g. one saved from an earlier autotune):
  * variants[n_ops], -1 = heuristic.  An index that is not valid for its op is ROMP_EINVAL. */
 int  romp_net_set_tuned(romp_net* net, int B, const int32_t* variants, int n_ops);
+
+/* A net from a plan file written by romp_amd/export.py (the lowered program with its packed constants, buffer
+ * initialisers and measured variant tables): what the reference's exported ROMP.onnx is to its ort_session
+ * (model.py:484-497, main.py:89,109) -- the model is converted once, the inference host needs only this library.
+ * The net owns the constants.  romp_net_plan_info: the input side length and the per-image sizes of the two outputs
+ * recorded in the file (0 for a net that was not loaded from a file), and the op count. */
+int  romp_net_load(romp_net** out, const char* path, int max_batch);
+int  romp_net_plan_info(romp_net* net, int32_t* input_size, int64_t* center_floats, int64_t* params_floats, int32_t* n_ops);
 /* Time a forward per op (HIP events on `stream` around every op, ops serialised on that stream): ms_out_host[n_ops] = the
  * median of `iters` passes. */
 int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,

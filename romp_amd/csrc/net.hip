@@ -12,6 +12,8 @@
 #include <map>
 #include <tuple>
 #include <string.h>
+#include <stdio.h>
+#include <stdint.h>
 
 namespace romp {
 
@@ -58,6 +60,11 @@ struct romp_net {
     hipEvent_t ev_begin = nullptr, ev_offset = nullptr, ev_done = nullptr;
     std::map<int, std::vector<int>> tuned;   // batch -> variant per op (-1: heuristic)
     std::map<GraphKey, hipGraphExec_t> graphs;
+    // a net loaded from a plan file (romp_net_load) owns its constants; one built by romp_net_create borrows the host's
+    void* plan_dev = nullptr;
+    std::vector<char> plan_host;
+    int32_t plan_input_size = 0;
+    int64_t plan_center_floats = 0, plan_params_floats = 0;
 };
 
 // Arena buffers are batch-major: image b of buffer `buf` starts at b * buf_floats[buf].  `b0` is the
@@ -516,6 +523,7 @@ void romp_net_destroy(romp_net* n) {
     for (float* p : n->bufs)
         if (p) hipFree(p);
     if (n->queues) hipFree(n->queues);
+    if (n->plan_dev) hipFree(n->plan_dev);
     for (int l = 0; l < 2; ++l) {
         for (int k = 0; k < 3; ++k) {
             if (n->side[l][k]) hipStreamDestroy(n->side[l][k]);
@@ -568,6 +576,113 @@ int romp_net_tuned_variant(romp_net* n, int B, int op_index) {
     if (!n || op_index < 0 || op_index >= (int)n->ops.size()) return -1;
     const std::vector<int>* tv = tuned_for(n, B);
     return tv ? (*tv)[op_index] : -1;
+}
+
+// ---- plan files --------------------------------------------------------------------------------------------------
+// The reference exports its network once (ROMPv1 -> ROMP.onnx, model.py:484-497) and its inference entry point then needs
+// no model code (main.py:89,109).  The counterpart here: `romp_amd/export.py` writes the lowered program -- ops, arena
+// sizes, packed constants, buffer initialisers, measured variant tables -- to one file; romp_net_load() builds a net from
+// it with nothing but this library.  Layout (little endian, see export.py): PlanHeader, int64 buf_floats[n_bufs],
+// romp_op ops[n_ops] whose pointer fields hold (offset + 1) into the device blob, or that with bit 63 set into the host
+// blob (0 = null), PlanInit inits[n_inits], int32 tuned[n_tuned][2 + n_ops] (batch, n_variants at export, variant per op),
+// device blob, host blob.
+struct PlanHeader {
+    char magic[8];                      // "ROMPPLAN"
+    uint32_t version, abi, n_ops, n_bufs, n_inits, n_tuned, input_size, op_bytes;
+    uint64_t center_floats, params_floats, dev_bytes, host_bytes;
+};
+struct PlanInit { int32_t buf; int32_t pad; uint64_t floats; uint64_t dev_off; };   // per-image content, replicated for every image
+
+int romp_net_load(romp_net** out, const char* path, int max_batch) {
+    ROMP_REQUIRE(out && path && max_batch > 0, "romp_net_load: bad arguments");
+    FILE* f = fopen(path, "rb");
+    ROMP_REQUIRE(f, "romp_net_load: cannot open %s", path);
+    std::vector<char> file;
+    {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        file.resize(sz > 0 ? (size_t)sz : 0);
+        const size_t got = file.empty() ? 0 : fread(file.data(), 1, file.size(), f);
+        fclose(f);
+        ROMP_REQUIRE(got == file.size() && file.size() >= sizeof(PlanHeader), "romp_net_load: %s is truncated", path);
+    }
+    PlanHeader h;
+    memcpy(&h, file.data(), sizeof(h));
+    ROMP_REQUIRE(memcmp(h.magic, "ROMPPLAN", 8) == 0 && h.version == 1, "romp_net_load: %s is not a version-1 plan file", path);
+    ROMP_REQUIRE(h.abi == ROMP_ABI_VERSION && h.op_bytes == sizeof(romp_op), "romp_net_load: plan was written for ABI %u (romp_op %u bytes), this library is ABI %d (%zu bytes)",
+                 h.abi, h.op_bytes, ROMP_ABI_VERSION, sizeof(romp_op));
+    size_t at = sizeof(PlanHeader);
+    const size_t need = at + (size_t)h.n_bufs * 8 + (size_t)h.n_ops * sizeof(romp_op) + (size_t)h.n_inits * sizeof(PlanInit) +
+                        (size_t)h.n_tuned * (2 + h.n_ops) * 4 + h.dev_bytes + h.host_bytes;
+    ROMP_REQUIRE(h.n_ops > 0 && need == file.size(), "romp_net_load: %s: size %zu does not match its header (%zu)", path, file.size(), need);
+    std::vector<int64_t> buf_floats(h.n_bufs);
+    memcpy(buf_floats.data(), file.data() + at, (size_t)h.n_bufs * 8); at += (size_t)h.n_bufs * 8;
+    std::vector<romp_op> ops(h.n_ops);
+    memcpy(ops.data(), file.data() + at, (size_t)h.n_ops * sizeof(romp_op)); at += (size_t)h.n_ops * sizeof(romp_op);
+    std::vector<PlanInit> inits(h.n_inits);
+    if (h.n_inits) memcpy(inits.data(), file.data() + at, (size_t)h.n_inits * sizeof(PlanInit));
+    at += (size_t)h.n_inits * sizeof(PlanInit);
+    const int32_t* tuned = reinterpret_cast<const int32_t*>(file.data() + at); at += (size_t)h.n_tuned * (2 + h.n_ops) * 4;
+    const char* dev_src = file.data() + at; at += h.dev_bytes;
+    const char* host_src = file.data() + at;
+    void* dev = nullptr;
+    if (h.dev_bytes) {
+        ROMP_HIP_CHECK(hipMalloc(&dev, h.dev_bytes));
+        if (hipMemcpy(dev, dev_src, h.dev_bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(dev); set_error("romp_net_load: upload failed"); return ROMP_EHIP; }
+    }
+    std::vector<char> host(host_src, host_src + h.host_bytes);
+    bool bad = false;
+    auto fix = [&](const void* field) -> const void* {
+        const uint64_t v = (uint64_t)(uintptr_t)field;
+        if (v == 0) return nullptr;
+        const bool on_host = (v >> 63) != 0;
+        const uint64_t off = (v & ~(1ull << 63)) - 1;
+        if (off >= (on_host ? h.host_bytes : h.dev_bytes)) { bad = true; return nullptr; }
+        return on_host ? (const void*)(host.data() + off) : (const void*)((const char*)dev + off);
+    };
+    for (romp_op& op : ops) {
+        op.weight = (const float*)fix(op.weight); op.scale = (const float*)fix(op.scale); op.shift = (const float*)fix(op.shift);
+        op.weight_aux = fix(op.weight_aux); op.weight_h2 = fix(op.weight_h2); op.scale_h2 = (const float*)fix(op.scale_h2);
+    }
+    if (bad) { if (dev) hipFree(dev); set_error("romp_net_load: %s: a constant lies outside its blob", path); return ROMP_EINVAL; }
+    romp_net* n = nullptr;
+    int rc = romp_net_create(&n, ops.data(), (int)h.n_ops, buf_floats.data(), (int)h.n_bufs, max_batch);
+    if (rc) { if (dev) hipFree(dev); return rc; }
+    n->plan_dev = dev;
+    n->plan_host.swap(host);            // (vector swap keeps the storage address: the ops' host pointers stay valid)
+    n->plan_input_size = (int32_t)h.input_size;
+    n->plan_center_floats = (int64_t)h.center_floats;
+    n->plan_params_floats = (int64_t)h.params_floats;
+    for (const PlanInit& in : inits) {
+        if (in.buf < 0 || in.buf >= (int)h.n_bufs || (int64_t)in.floats > buf_floats[in.buf] || in.dev_off + in.floats * 4 > h.dev_bytes) {
+            set_error("romp_net_load: %s: bad buffer initialiser", path);
+            romp_net_destroy(n);
+            return ROMP_EINVAL;
+        }
+        for (int b = 0; b < max_batch; ++b)
+            if (hipMemcpy(n->bufs[in.buf] + (size_t)b * buf_floats[in.buf], (const char*)dev + in.dev_off, in.floats * 4, hipMemcpyDeviceToDevice) != hipSuccess) {
+                set_error("romp_net_load: buffer initialiser copy failed");
+                romp_net_destroy(n);
+                return ROMP_EHIP;
+            }
+    }
+    for (uint32_t t = 0; t < h.n_tuned; ++t) {      // measured variant tables: only if this build still has the same kernels
+        const int32_t* row = tuned + (size_t)t * (2 + h.n_ops);
+        if (row[1] != conv_num_variants() || row[0] <= 0 || row[0] > max_batch) continue;
+        if (romp_net_set_tuned(n, row[0], row + 2, (int)h.n_ops) != ROMP_OK) n->tuned.erase(row[0]);
+    }
+    *out = n;
+    return ROMP_OK;
+}
+
+int romp_net_plan_info(romp_net* n, int32_t* input_size, int64_t* center_floats, int64_t* params_floats, int32_t* n_ops) {
+    ROMP_REQUIRE(n, "romp_net_plan_info: null net");
+    if (input_size) *input_size = n->plan_input_size;
+    if (center_floats) *center_floats = n->plan_center_floats;
+    if (params_floats) *params_floats = n->plan_params_floats;
+    if (n_ops) *n_ops = (int32_t)n->ops.size();
+    return ROMP_OK;
 }
 
 int romp_net_set_tuned(romp_net* n, int B, const int32_t* variants, int n_ops) {

@@ -58,6 +58,9 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
                         help='[romp_amd] hrnet32: the simple_romp model (ROMP.pkl); resnet50: the training tree\'s ResNet-50 variant '
                              '(romp/lib/models/resnet_50.py + romp_model.py state_dict)')
+    parser.add_argument('--plan_path', type=str, default=None,
+                        help='[romp_amd] start from a plan file (python -m romp_amd.export: the lowered network with its packed constants '
+                             'and measured kernel tables) instead of --model_path: the counterpart of the reference\'s --onnx / --model_onnx_path')
     parser.add_argument('--host_preprocess', action='store_true', help='[romp_amd] pad/resize on the host (cv2 / numpy) instead of the device kernel')
     args = parser.parse_args(input_args)
     if not torch.cuda.is_available():
@@ -91,7 +94,11 @@ class ROMP(nn.Module):
         self._initilization_(smpl_model)
 
     def _build_model_(self, state_dict=None):
-        """main.py:72-77: load the state_dict and bind it into the HIP network context."""
+        """main.py:72-77: load the state_dict and bind it into the HIP network context (or, like the reference's ONNX branch
+        main.py:86-89, start from the exported plan file)."""
+        if state_dict is None and getattr(self.settings, 'plan_path', None):
+            self.model = RompNet.from_plan(self.settings.plan_path, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32))
+            return
         if state_dict is None:
             state_dict = torch.load(self.settings.model_path, map_location='cpu')
         builder = None

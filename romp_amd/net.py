@@ -57,6 +57,41 @@ class RompNet:
         if use_graph:
             self.set_graph(True)
 
+    @classmethod
+    def from_plan(cls, path, device, max_batch=32, use_graph=False, out_shapes=None):
+        """A net from a plan file (export.save_plan): no state_dict, no lowering -- libromp_hip.so's romp_net_load does it all.
+        Variant tables measured before the export are installed when the file was written by the same build."""
+        from types import SimpleNamespace
+        from .export import read_plan
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
+        self.lib = L.load()
+        self.max_batch = int(max_batch)
+        plan = read_plan(path)
+        ops = plan['ops']
+        self.bf16x3 = any(o.weight_h2 or o.weight_aux for o in ops)
+        self.split, self.split_k, self.input_size = 1, int(any(o.kind == L.OP_KSUM for o in ops)), plan['input_size']
+        buf_fmt = {}
+        for o in ops:
+            if o.out_buf >= 0:
+                buf_fmt[o.out_buf] = o.out_fmt
+        self.program = SimpleNamespace(ops=list(ops), names=['op%d' % i for i in range(len(ops))], buf_floats=plan['buf_floats'],
+                                       buf_fmt=buf_fmt, flops=[0.0] * len(ops), bytes=[0.0] * len(ops), coord_off=None)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.romp_net_load(C.byref(h), str(path).encode(), self.max_batch))
+        self._h = h
+        n_variants = self.lib.romp_conv_num_variants()
+        self._tuned = {B for B, (nv, _) in plan['tuned'].items() if nv == n_variants and B <= self.max_batch}
+        ms = self.input_size // 8
+        cf, pf = plan['center_floats'], plan['params_floats']
+        self.out_shapes = out_shapes or (((ms, ms), (ms, ms, pf // (ms * ms))) if cf == ms * ms and pf % (ms * ms) == 0 else ((cf,), (pf,)))
+        if use_graph:
+            self.set_graph(True)
+        return self
+
     # -- configuration -------------------------------------------------------------------
     def set_mode(self, mode):
         """0 = MFMA kernels (default), 1 = naive direct-conv cross-check kernels."""

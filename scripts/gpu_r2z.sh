@@ -1,7 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 export PYTHONUNBUFFERED=1
-for i in 1 2; do
-python scripts/latency_breakdown.py 2>&1 | grep "graph 1 streams 1"
-ROMP_CONV_DEBUG=512 python scripts/latency_breakdown.py 2>&1 | grep "graph 1 streams 1" | sed 's/^/prefetch off: /'
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "plan_file"; timeout 600 python -m pytest tests/test_gpu_bev.py -q -x -m gpu -k "plan_file" 2>&1 | tail -8 2>&1 | tail -15

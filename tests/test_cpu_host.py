@@ -294,3 +294,43 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             if op.out_buf >= 0:
                 written[op.out_buf] = L.FMT_F32
     assert n_h2 > 50, n_h2
+
+
+def test_plan_file_roundtrip_on_host(tmp_path):
+    """export.save_plan / read_plan: every op field and every constant of the lowered ROMP program (single-image plan with
+    split-K layers, f16x2 weights) survives the file; pointer fields become blob offsets; the head input's CoordConv
+    channels travel as a buffer initialiser."""
+    import ctypes as C
+    from romp_amd import export, lib as L
+    from romp_amd import synthetic as S
+    from romp_amd.plan import build_romp_hrnet32, coord_channels, encode_h2
+    P = build_romp_hrnet32(S.make_romp_state_dict(0), 'cpu', 512, bf16x3='f16x2', split_k_items=128)
+    path = str(tmp_path / 'romp_b1.plan')
+    export.save_plan(P, path, tuned={1: [-1] * len(P.ops)})
+    plan = export.read_plan(path)
+    ops = P.op_array()
+    assert plan['abi'] == L.ABI_VERSION and plan['input_size'] == 512 and plan['buf_floats'] == list(P.buf_floats)
+    assert (plan['center_floats'], plan['params_floats']) == (64 * 64, 64 * 64 * 145) and list(plan['tuned']) == [1]
+    by_ptr = {c.data_ptr(): c for c in P.consts if hasattr(c, 'data_ptr')}
+    checked = 0
+    for a, b in zip(ops, plan['ops']):
+        for name, _ in L.RompOp._fields_:
+            va, vb = getattr(a, name), getattr(b, name)
+            if name in export.PTR_FIELDS:
+                assert bool(va) == bool(vb)
+                if va:
+                    t = by_ptr[va]
+                    raw = export.decode_pointer(plan, vb, t.numel() * t.element_size())
+                    assert raw == t.contiguous().view(torch.uint8).numpy().tobytes()
+                    checked += 1
+            elif hasattr(va, '__len__'):
+                assert list(va) == list(vb), name
+            else:
+                assert va == vb, name
+    assert checked > 600
+    (buf, floats, off), = plan['inits']
+    coords = coord_channels(1, 128, 'cpu', P.head_in_ch, P.coord_off)
+    if P.buf_fmt.get(P.head_in_buf) == L.FMT_H2:
+        coords = encode_h2(coords)
+    assert buf == P.head_in_buf and floats == coords.numel()
+    assert plan['dev'][off:off + 4 * floats] == coords.contiguous().view(torch.uint8).numpy().tobytes()

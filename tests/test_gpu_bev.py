@@ -279,3 +279,17 @@ def test_bev_temporal_and_render(dev):
         print('   rendered_image vs oracle pipeline: differing bytes %d, painted px %d' % (nd, int((ref != frame).any(2).sum())))
         assert nd <= 3 * 8                                                  # a vertex within 1 ulp of a pixel centre may flip a pixel
     assert len(all_ids) >= 1
+
+
+def test_bev_plan_file_roundtrip(dev, bev_model, tmp_path):
+    """The BEV program carries HOST-side constant tables (scale anchors, the Conv3d refiners' weights) next to its device
+    constants: both blobs of the plan file; romp_net_load gives bit-identical 3-D maps."""
+    from romp_amd.export import save_plan
+    from romp_amd.net import RompNet
+    img = O.make_images(2, seed=4).to(dev)
+    c0, m0 = bev_model.localization(img)
+    path = str(tmp_path / 'bev.plan')
+    save_plan(bev_model.net, path)
+    net2 = RompNet.from_plan(path, dev, max_batch=2, out_shapes=bev_model.net.out_shapes)
+    c1, m1 = net2.forward_nhwc(img)
+    assert c1.shape == c0.shape and torch.equal(c1, c0) and torch.equal(m1, m0)

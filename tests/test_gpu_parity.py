@@ -421,6 +421,62 @@ def test_net_split_k_single_image(dev, golden_dir, conv_math):
     assert RompNet(sd, dev, max_batch=4).split_k == 0
 
 
+def test_plan_file_c_abi_only(dev, tmp_path):
+    """export.save_plan -> romp_net_load: a net created by the C ABI from the file alone (no state_dict, no lowering) gives
+    BIT-IDENTICAL maps to the net the file was exported from, for the batch plan (autotuned table travels) and for the
+    single-image split-K plan; and through RompNet.from_plan."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.export import save_plan
+    from romp_amd.net import RompNet
+    lib = L.load()
+    sd = O.make_romp_state_dict(0)
+    for max_batch, B in ((4, 3), (1, 1)):
+        net = RompNet(sd, dev, max_batch=max_batch, bf16x3='f16x2')
+        img = O.make_images(B, seed=5).to(dev)
+        c0, p0 = net.forward_nhwc(img)                       # (autotunes B: the table goes into the file)
+        path = str(tmp_path / ('romp_b%d.plan' % max_batch))
+        save_plan(net, path)
+        h = C.c_void_p()
+        L.check(lib.romp_net_load(C.byref(h), path.encode(), max_batch))
+        try:
+            size, cf, pf, n_ops = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
+            L.check(lib.romp_net_plan_info(h, C.byref(size), C.byref(cf), C.byref(pf), C.byref(n_ops)))
+            assert (size.value, cf.value, pf.value, n_ops.value) == (512, 64 * 64, 64 * 64 * 145, len(net.program.ops))
+            assert [lib.romp_net_tuned_variant(h, B, i) for i in range(n_ops.value)] == net.tuned_variants(B)
+            c1, p1 = torch.empty_like(c0), torch.empty_like(p0)
+            L.check(lib.romp_net_forward(h, L.ptr(img), B, L.ptr(c1), L.ptr(p1), L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            assert torch.equal(c1, c0) and torch.equal(p1, p0)
+        finally:
+            lib.romp_net_destroy(h)
+        net2 = RompNet.from_plan(path, dev, max_batch=max_batch)
+        c2, p2 = net2.forward_nhwc(img)
+        assert torch.equal(c2, c0) and torch.equal(p2, p0) and net2.split_k == (1 if max_batch == 1 else 0)
+    # the drop-in API from the plan file (the reference's --onnx branch, main.py:86-89): same result dict as from the state_dict
+    import romp_amd
+    rs = np.random.RandomState(0)
+    frame = rs.randint(0, 256, (360, 640, 3)).astype(np.uint8)
+    sd2 = O.make_romp_state_dict(0, center_bias=2.0)
+    path2 = str(tmp_path / 'romp_api.plan')
+    outs = []
+    for kw in (dict(state_dict=sd2), dict()):
+        s_ = romp_amd.romp_settings([] if kw else ['--plan_path', path2])
+        s_.GPU, s_.center_thresh, s_.max_batch = 0, 1.25, 1
+        m_ = romp_amd.ROMP(s_, smpl_model=O.make_synthetic_smpl(0), **kw)
+        outs.append(m_(frame))
+        if kw:
+            save_plan(m_.model, path2)                       # with the kernel table its first forward measured
+    assert outs[0] is not None and set(outs[0]) == set(outs[1])
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    # a truncated file is refused with a message, not a crash
+    bad = str(tmp_path / 'bad.plan')
+    open(bad, 'wb').write(open(path, 'rb').read()[:-100])
+    h = C.c_void_p()
+    assert lib.romp_net_load(C.byref(h), bad.encode(), 1) != 0 and b'size' in lib.romp_last_error()
+
+
 def test_net_batch_lanes(dev):
     """set_split(2): the forward runs as two half-batch lanes on two streams (convs capped at one
     workgroup per CU).  Same maps as the oracle for every image of the batch, eagerly and from a hipGraph;
