@@ -477,6 +477,37 @@ def test_plan_file_c_abi_only(dev, tmp_path):
     assert lib.romp_net_load(C.byref(h), bad.encode(), 1) != 0 and b'size' in lib.romp_last_error()
 
 
+def test_c_host_without_python(dev, tmp_path):
+    """examples/host_no_python.cpp: a compiled host that knows only include/romp_hip.h and a plan file (romp_net_load ->
+    romp_net_forward (graph replay) -> romp_parse) must write the same bytes as the Python path."""
+    import subprocess
+    from romp_amd.export import save_plan
+    from romp_amd.net import RompNet
+    from romp_amd.post_parser import CenterMap, parsing_outputs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'host_no_python')
+    r = subprocess.run(['hipcc', '--offload-arch=gfx950', '-O2', '-I', os.path.join(root, 'include'), os.path.join(root, 'examples', 'host_no_python.cpp'),
+                        '-L', os.path.join(root, 'romp_amd'), '-lromp_hip', '-Wl,-rpath,' + os.path.join(root, 'romp_amd'), '-o', exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    net = RompNet(sd, dev, max_batch=2, bf16x3='f16x2')
+    img = O.make_images(2, seed=7)
+    c0, p0 = net.forward_nhwc(img.to(dev))
+    ref = parsing_outputs(c0.unsqueeze(1), p0, CenterMap(1.25))
+    plan, frames, prefix = str(tmp_path / 'net.plan'), str(tmp_path / 'frames.f32'), str(tmp_path / 'out')
+    save_plan(net, plan)
+    img.numpy().astype(np.float32).tofile(frames)
+    r = subprocess.run([exe, plan, frames, '2', '1.25', prefix], capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.fromfile(prefix + '.center.f32', np.float32), c0.cpu().numpy().ravel())
+    assert ref is not None
+    assert np.array_equal(np.fromfile(prefix + '.thetas.f32', np.float32), ref['smpl_thetas'].cpu().numpy().ravel())
+    assert np.array_equal(np.fromfile(prefix + '.cam.f32', np.float32), ref['cam'].cpu().numpy().ravel())
+    assert len(np.fromfile(prefix + '.flat.i32', np.int32)) == ref['cam'].shape[0]
+
+
 def test_net_batch_lanes(dev):
     """set_split(2): the forward runs as two half-batch lanes on two streams (convs capped at one
     workgroup per CU).  Same maps as the oracle for every image of the batch, eagerly and from a hipGraph;
