@@ -76,7 +76,7 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------ roofline
 def kernel_of(variant_name):
     import re
-    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2o|h2|h2d|h2p|h2w|h2q)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
     fam, ks, s, mt, nt, tw, ck = m.groups()
@@ -84,8 +84,8 @@ def kernel_of(variant_name):
         return 'conv_h2q_kernel<%s, %s, %s>' % (mt, nt, tw)
     if fam in ('h2p', 'h2w'):
         return 'conv_h2p_kernel<%s, %s, %s, %s>' % (mt, nt, tw, 'true' if fam == 'h2w' else 'false')
-    if fam == 'h2o':
-        fam = 'h2o4'
+    if fam in ('h2o', 'h2do'):
+        fam += '4'
     return 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % (fam, ks, s, mt, nt, tw, ck)
 
 

@@ -254,7 +254,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 7 ? "conv_h2q" : v.math == 6 ? "conv_h2w" : v.math == 5 ? "conv_h2p" : v.math == 4 ? "conv_h2d" : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 7 ? "conv_h2q" : v.math == 6 ? "conv_h2w" : v.math == 5 ? "conv_h2p" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }
