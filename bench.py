@@ -112,7 +112,7 @@ def pmc_traffic(variant_name, pmc_dir):
     return dict(bytes=2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'], kernel=kern)
 
 
-def roofline_report(net, images):
+def roofline_report(net, images, pmc_workload=False):
     """Per kernel variant: sum of algorithmic FLOPs / bytes over its launches / sum of HIP-event durations (events recorded
     on the launch stream around every layer kernel, ops serialised on one stream)."""
     B = images.shape[0]
@@ -152,7 +152,12 @@ def roofline_report(net, images):
                 launches=a['launches'], avg_launch_ms=round(a['ms'] / a['launches'], 5),
                 flops_per_launch=a['flops'] / a['launches'], alg_bytes_per_launch=a['bytes'] / a['launches'],
                 net_ms_per_batch=round(sum(ms), 3), batch=B)
-    t = pmc_traffic(name, os.path.join(ROOT, 'profiles'))
+    # PMC counters cannot be read from inside the process: `traffic` comes from the committed rocprofv3 --pmc passes of the
+    # DEFAULT workload (profiles/README.md) and is reported only for that workload (a kernel name alone does not identify the
+    # layers behind it: the ResNet-50 / BEV / other-batch lines carry null) and only if the dominant kernel is in those passes
+    t = pmc_traffic(name, os.path.join(ROOT, 'profiles')) if pmc_workload else None
+    if not pmc_workload:
+        roof['traffic_note'] = 'null: the committed PMC passes (profiles/%s_pmc_*) are of the default HRNet-32 batch-32 workload' % PROFILE_TAG
     if t is not None:                        # measured in a separate rocprofv3 --pmc pass of this command (profiles/README.md)
         roof['traffic'] = round(t['bytes'])
         roof['traffic_source'] = 'profiles/%s_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % (PROFILE_TAG, t['kernel'])
@@ -565,7 +570,7 @@ def main():
         first = images[:B]
         if not args.no_roofline:
             with torch.cuda.stream(stream):
-                roof, classes = roofline_report(model.model, first)
+                roof, classes = roofline_report(model.model, first, pmc_workload=(args.backbone == 'hrnet32' and B == 32))
             result['roofline'] = roof
             result['kernel_classes'] = classes
         if not args.no_parity:
