@@ -89,7 +89,7 @@ def kernel_of(variant_name):
     return 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % (fam, ks, s, mt, nt, tw, ck)
 
 
-def pmc_traffic(variant_name, pmc_dir):
+def pmc_traffic(variant_name, pmc_dir, workload=''):
     """HBM bytes per launch of the kernel behind `variant_name` from the committed rocprofv3 PMC passes
     (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv, produced by scripts/gpu_profile.sh: separate --pmc passes of
     this same command; unit KiB per dispatch; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).
@@ -101,7 +101,7 @@ def pmc_traffic(variant_name, pmc_dir):
         return None
     vals = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
-        path = os.path.join(pmc_dir, '%s_pmc_%s_by_kernel.csv' % (PROFILE_TAG, counter))
+        path = os.path.join(pmc_dir, '%s%s_pmc_%s_by_kernel.csv' % (PROFILE_TAG, workload, counter))
         if not os.path.exists(path):
             return None
         for row in csv.DictReader(open(path)):
@@ -112,7 +112,7 @@ def pmc_traffic(variant_name, pmc_dir):
     return dict(bytes=2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'], kernel=kern)
 
 
-def roofline_report(net, images, pmc_workload=False):
+def roofline_report(net, images, pmc_workload=None):
     """Per kernel variant: sum of algorithmic FLOPs / bytes over its launches / sum of HIP-event durations (events recorded
     on the launch stream around every layer kernel, ops serialised on one stream)."""
     B = images.shape[0]
@@ -155,12 +155,13 @@ def roofline_report(net, images, pmc_workload=False):
     # PMC counters cannot be read from inside the process: `traffic` comes from the committed rocprofv3 --pmc passes of the
     # DEFAULT workload (profiles/README.md) and is reported only for that workload (a kernel name alone does not identify the
     # layers behind it: the ResNet-50 / BEV / other-batch lines carry null) and only if the dominant kernel is in those passes
-    t = pmc_traffic(name, os.path.join(ROOT, 'profiles')) if pmc_workload else None
-    if not pmc_workload:
-        roof['traffic_note'] = 'null: the committed PMC passes (profiles/%s_pmc_*) are of the default HRNet-32 batch-32 workload' % PROFILE_TAG
+    # pmc_workload: '' = the default workload, '_resnet50' / '_bev' = their own passes, None = no passes for this configuration
+    t = pmc_traffic(name, os.path.join(ROOT, 'profiles'), pmc_workload) if pmc_workload is not None else None
+    if pmc_workload is None:
+        roof['traffic_note'] = 'null: no committed PMC passes (profiles/%s*_pmc_*) for this configuration' % PROFILE_TAG
     if t is not None:                        # measured in a separate rocprofv3 --pmc pass of this command (profiles/README.md)
         roof['traffic'] = round(t['bytes'])
-        roof['traffic_source'] = 'profiles/%s_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % (PROFILE_TAG, t['kernel'])
+        roof['traffic_source'] = 'profiles/%s%s_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % (PROFILE_TAG, pmc_workload, t['kernel'])
         roof['traffic_over_algorithmic'] = round(t['bytes'] / (a['bytes'] / a['launches']), 3)
     return roof, classes
 
@@ -423,7 +424,7 @@ def bench_bev(args, dev):
     if not args.no_roofline:
         s1 = torch.cuda.Stream(dev)
         with torch.cuda.stream(s1):
-            roof, classes = roofline_report(net, images)
+            roof, classes = roofline_report(net, images, pmc_workload='_bev' if args.batch == 32 else None)
             ms = net.profile(images, iters=2)
         head_ms = sum(t for t, nm in zip(ms, net.program.names) if nm.startswith('bev.'))
         c3 = [(t, by) for t, nm, by in zip(ms, net.program.names, net.program.bytes) if 'refine' in nm]
@@ -570,7 +571,7 @@ def main():
         first = images[:B]
         if not args.no_roofline:
             with torch.cuda.stream(stream):
-                roof, classes = roofline_report(model.model, first, pmc_workload=(args.backbone == 'hrnet32' and B == 32))
+                roof, classes = roofline_report(model.model, first, pmc_workload=(None if B != 32 else '' if args.backbone == 'hrnet32' else '_' + args.backbone))
             result['roofline'] = roof
             result['kernel_classes'] = classes
         if not args.no_parity:
