@@ -184,7 +184,10 @@ int  romp_conv_describe(const romp_op* op_host, int B, int variant, char* out_ho
  * score-descending inside an image; ties broken by lower flat index.
  *   center_maps (B,64,64)      params_maps (B,64,64,145) NHWC, scale channel NOT yet 1.1**
  *   batch_ids/flat_inds int32 (N)   scores (N)   params_pred (N,145) (scale already 1.1**s)
- *   cam (N,3)  thetas (N,72)  betas (N,10)  center_preds int32 (N,2)  */
+ *   cam (N,3)  thetas (N,72)  betas (N,10)  center_preds int32 (N,2)
+ * count_host == NULL: asynchronous form (no copy, no synchronisation): image b's count stays on the device in
+ * workspace[b*(2*max_person+2) + 2*max_person]; rows past the count are left untouched.  The single-image path uses it to
+ * enqueue the whole post-processing for `max_person` rows while the network still runs, with ONE sync at the end. */
 int  romp_parse(const float* center_maps, const float* params_maps_nhwc, int B,
                 float conf_thresh, int max_person, int32_t* count_host,
                 int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,

@@ -260,7 +260,7 @@ int romp_project_verts(const float* verts, int N, int V, const float* cam, const
 int romp_parse(const float* center_maps, const float* params_maps, int B, float conf_thresh, int max_person,
                int32_t* count_host, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
                float* cam, float* thetas, float* betas, int32_t* center_preds, int32_t* workspace, void* stream) {
-    ROMP_REQUIRE(center_maps && params_maps && count_host && workspace && B > 0, "romp_parse: bad arguments");
+    ROMP_REQUIRE(center_maps && params_maps && workspace && B > 0, "romp_parse: bad arguments");
     ROMP_REQUIRE(max_person >= 1 && max_person <= 1024, "romp_parse: max_person %d out of range", max_person);
     ROMP_REQUIRE(batch_ids && flat_inds && scores && params_pred && cam && thetas && betas && center_preds,
                  "romp_parse: null output");
@@ -270,6 +270,7 @@ int romp_parse(const float* center_maps, const float* params_maps, int B, float 
     hipLaunchKernelGGL(parse_pack_kernel, dim3(max_person, B), dim3(64), 0, st, center_maps, params_maps, B, max_person,
                        workspace, batch_ids, flat_inds, scores, params_pred, cam, thetas, betas, center_preds);
     ROMP_HIP_CHECK(hipGetLastError());
+    if (!count_host) return ROMP_OK;     // asynchronous form: image b's count stays in workspace[b * (2 * max_person + 2) + 2 * max_person]
     std::vector<int32_t> cnt((size_t)B * (2 * max_person + 2));
     ROMP_HIP_CHECK(hipMemcpyAsync(cnt.data(), workspace, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ROMP_HIP_CHECK(hipStreamSynchronize(st));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench.py under the driver's multi-GPU launcher (one rank here: the RCCL init / all-gather path with world size 1)
 cd "$(dirname "$0")/.."
 export PYTHONUNBUFFERED=1
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-f32-companion --no-latency --no-end-to-end 2>&1 | tail -3 | cut -c1-900
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -s -k "fast_path or romp_api or romp_end" 2>&1 | tail -12
+timeout 300 python scripts/latency_b1.py 2>&1 | tail -2

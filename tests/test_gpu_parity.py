@@ -508,6 +508,32 @@ def test_c_host_without_python(dev, tmp_path):
     assert len(np.fromfile(prefix + '.flat.i32', np.int32)) == ref['cam'].shape[0]
 
 
+def test_romp_api_fast_path(dev):
+    """ROMP(settings)(frame) takes the latency-arranged path by default (everything enqueued for all candidate rows, one
+    synchronisation): its result dict must be the standard flow's, key for key and byte for byte, over several frames
+    (stale candidate rows from earlier frames must not leak), including the nobody-detected case."""
+    import romp_amd
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    smpl = O.make_synthetic_smpl(0)
+    s = romp_amd.romp_settings([])
+    s.GPU, s.center_thresh, s.max_batch = 0, 1.25, 1
+    model = romp_amd.ROMP(s, state_dict=sd, smpl_model=smpl)
+    rs = np.random.RandomState(5)
+    for shape in ((360, 640, 3), (720, 1280, 3), (512, 512, 3), (300, 200, 3)):
+        frame = rs.randint(0, 256, shape).astype(np.uint8)
+        model.fast_single = True
+        a = model(frame)
+        model.fast_single = False
+        b = model(frame)
+        assert a is not None and b is not None and set(a) == set(b), (set(a), set(b))
+        for k in b:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        print('frame', shape, ':', a['cam'].shape[0], 'persons, fast path == standard path')
+    model.centermap_parser.conf_thresh = 1e3
+    model.fast_single = True
+    assert model(frame) is None
+
+
 def test_net_batch_lanes(dev):
     """set_split(2): the forward runs as two half-batch lanes on two streams (convs capped at one
     workgroup per CU).  Same maps as the oracle for every image of the batch, eagerly and from a hipGraph;
