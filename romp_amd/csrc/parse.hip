@@ -24,7 +24,8 @@ namespace romp {
 constexpr int MAP = 64, NPIX = MAP * MAP;
 
 // ws layout per image: [max_person] flat index, [max_person] score bits, [1] count, [1] total candidates
-__global__ __launch_bounds__(256) void parse_nms_topk_kernel(const float* __restrict__ center, float thresh,
+constexpr int PARSE_THREADS = 1024;     // one workgroup per image; 4 pixels per thread (256 threads: 20 us on the single-image critical path)
+__global__ __launch_bounds__(PARSE_THREADS) void parse_nms_topk_kernel(const float* __restrict__ center, float thresh,
                                                               int max_person, int32_t* __restrict__ ws) {
     __shared__ float s_map[NPIX];
     __shared__ float s_score[NPIX];
@@ -32,10 +33,10 @@ __global__ __launch_bounds__(256) void parse_nms_topk_kernel(const float* __rest
     __shared__ int s_count;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* cm = center + (size_t)b * NPIX;
-    for (int p = tid; p < NPIX; p += 256) s_map[p] = cm[p];
+    for (int p = tid; p < NPIX; p += PARSE_THREADS) s_map[p] = cm[p];
     if (tid == 0) s_count = 0;
     __syncthreads();
-    for (int p = tid; p < NPIX; p += 256) {
+    for (int p = tid; p < NPIX; p += PARSE_THREADS) {
         const int y = p / MAP, x = p % MAP;
         const float v = s_map[p];
         float m = v;                                   // MaxPool2d(5,1,2): implicit -inf padding
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void parse_nms_topk_kernel(const float* __rest
     __syncthreads();
     const int n = s_count;
     int32_t* w = ws + (size_t)b * (2 * max_person + 2);
-    for (int c = tid; c < n; c += 256) {
+    for (int c = tid; c < n; c += PARSE_THREADS) {
         const float sc = s_score[c];
         const int id = s_idx[c];
         int rank = 0;
@@ -265,7 +266,7 @@ int romp_parse(const float* center_maps, const float* params_maps, int B, float 
     ROMP_REQUIRE(batch_ids && flat_inds && scores && params_pred && cam && thetas && betas && center_preds,
                  "romp_parse: null output");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(parse_nms_topk_kernel, dim3(B), dim3(256), 0, st, center_maps, conf_thresh, max_person, workspace);
+    hipLaunchKernelGGL(parse_nms_topk_kernel, dim3(B), dim3(PARSE_THREADS), 0, st, center_maps, conf_thresh, max_person, workspace);
     ROMP_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(parse_pack_kernel, dim3(max_person, B), dim3(64), 0, st, center_maps, params_maps, B, max_person,
                        workspace, batch_ids, flat_inds, scores, params_pred, cam, thetas, betas, center_preds);

@@ -337,11 +337,27 @@ __global__ __launch_bounds__(256) void ksum_kernel(KsumParams p) {
         const int c = (int)(i % p.C8) * 8;
         const size_t pix = i / p.C8;
         const float* pp = p.part + pix * p.part_cs + c;
-        float4 va = ldg4(pp), vb = ldg4(pp + 4);
-        for (int g = 1; g < p.G; ++g) {
-            const float4 ta = ldg4(pp + (size_t)g * p.C), tb = ldg4(pp + (size_t)g * p.C + 4);
-            va.x += ta.x; va.y += ta.y; va.z += ta.z; va.w += ta.w;
-            vb.x += tb.x; vb.y += tb.y; vb.z += tb.z; vb.w += tb.w;
+        // eight slices per round, every load of a round issued before the first add (a rolled loop waited for each slice in
+        // turn: 4.7 us per launch on the single-image critical path); slices are added in order, as before
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        for (int g0 = 0; g0 < p.G; g0 += 8) {
+            float4 ta[8], tb[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int gg = min(g0 + g, p.G - 1);
+                ta[g] = ldg4(pp + (size_t)gg * p.C);
+                tb[g] = ldg4(pp + (size_t)gg * p.C + 4);
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g0 + g < p.G) {
+                    if (g0 + g == 0) { va = ta[0]; vb = tb[0]; }
+                    else {
+                        va.x += ta[g].x; va.y += ta[g].y; va.z += ta[g].z; va.w += ta[g].w;
+                        vb.x += tb[g].x; vb.y += tb[g].y; vb.z += tb[g].z; vb.w += tb[g].w;
+                    }
+                }
+            }
         }
         const float4 sa = ldg4(p.scale + c), sb = ldg4(p.scale + c + 4), ha = ldg4(p.shift + c), hb = ldg4(p.shift + c + 4);
         va = make_float4(fmaf(va.x, sa.x, ha.x), fmaf(va.y, sa.y, ha.y), fmaf(va.z, sa.z, ha.z), fmaf(va.w, sa.w, ha.w));
