@@ -334,3 +334,23 @@ def test_plan_file_roundtrip_on_host(tmp_path):
         coords = encode_h2(coords)
     assert buf == P.head_in_buf and floats == coords.numel()
     assert plan['dev'][off:off + 4 * floats] == coords.contiguous().view(torch.uint8).numpy().tobytes()
+
+
+def test_export_cli_bev_host_tables(tmp_path):
+    """python -m romp_amd.export on a BEV checkpoint without a GPU: the program's HOST-side tables (scale anchors, the Conv3d
+    refiners' weights) land in the plan's host blob and are referenced with the host bit set."""
+    from romp_amd import export, synthetic as S
+    from romp_amd.lib import OP_BEV_MAPS, OP_CONV3D
+    ckpt, plan_path = str(tmp_path / 'BEV.pth'), str(tmp_path / 'bev.plan')
+    torch.save(S.make_bev_state_dict(0), ckpt)
+    export.main(['--model_path', ckpt, '-o', plan_path, '--bev'])
+    plan = export.read_plan(plan_path)
+    assert (plan['center_floats'], plan['params_floats']) == (64 * 128 * 128, 3 * 64 * 128 * 128) and plan['inits'] == []
+    host_ops = [o for o in plan['ops'] if o.kind in (OP_BEV_MAPS, OP_CONV3D)]
+    assert len(host_ops) == 5 and all(o.weight & export.HOST_BIT for o in host_ops)
+    maps = [o for o in host_ops if o.kind == OP_BEV_MAPS][0]
+    anchors = np.frombuffer(export.decode_pointer(plan, maps.weight, 64 * 4), np.float32)
+    from romp_amd.bev_plan import cam3dmap_anchor
+    assert np.allclose(anchors, cam3dmap_anchor(60, 128))
+    dev_ops = [o for o in plan['ops'] if o.weight and not (o.weight & export.HOST_BIT)]
+    assert len(dev_ops) > 300
