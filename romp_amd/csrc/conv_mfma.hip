@@ -47,6 +47,7 @@ static void collect_variants() {
     t = conv_variants_h2(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2d(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2p(&n); kVariants.insert(kVariants.end(), t, t + n);
+    t = conv_variants_h2r(&n); kVariants.insert(kVariants.end(), t, t + n);
     kNumVariants = (int)kVariants.size();
 }
 static bool g_attr_done = false;
@@ -107,7 +108,8 @@ static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) 
     if ((v.math == 1 || v.math == 2) && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.math >= 3 && (op.weight_h2 == nullptr || op.scale_h2 == nullptr || (op.cin_pad & 15))) return false;
     if (op.in_fmt == ROMP_FMT_H2 && v.math < 3) return false;
-    if (v.math >= 5 && (op.in_fmt != ROMP_FMT_H2 || op.cin_pad < 32)) return false;   // the DMA pipeline copies pre-split pixels
+    if (v.math >= 5 && v.math != 8 && (op.in_fmt != ROMP_FMT_H2 || op.cin_pad < 32)) return false;
+    if (v.math == 8 && op.in_fmt != ROMP_FMT_H2) return false;                         // register-weight kernels: pixels arrive by LDS-DMA too   // the DMA pipeline copies pre-split pixels
     if (v.math == 6 && (op.cin_pad != 32 || op.cout_pad != v.nt * 32 || op.groups != 1)) return false;   // resident weights: one slab for every item          // only the f16x2 kernels stage pre-split activations
     if ((op.out_fmt == ROMP_FMT_H2 || op.res_fmt == ROMP_FMT_H2) && !(op.Cout == op.cout_pad)) return false;   // vector epilogue only
     if (v.ks != op.ksize || v.s != op.stride) return false;
@@ -144,8 +146,11 @@ static void out_dims(const romp_op& op, int* Ho, int* Wo) {
 int conv_num_variants() { collect_variants(); return kNumVariants; }
 
 bool conv_variant_valid(const romp_op& op, int variant);
+static int g_no_h2r = -1;                   // env ROMP_CONV_NO_H2R=1: keep the register-weight kernels (conv_h2r.hip) out of the autotuner (A/B runs)
 bool conv_variant_tunable(const romp_op& op, int variant) {
-    return conv_variant_valid(op, variant) && (kVariants[variant].math < 5 || pipe_in_autotune());
+    if (g_no_h2r < 0) { const char* e = getenv("ROMP_CONV_NO_H2R"); g_no_h2r = (e && atoi(e)) ? 1 : 0; }
+    if (kVariants[variant].math == 8 && g_no_h2r) return false;
+    return conv_variant_valid(op, variant) && (kVariants[variant].math < 5 || kVariants[variant].math == 8 || pipe_in_autotune());
 }
 
 bool conv_variant_valid(const romp_op& op, int variant) {
@@ -254,7 +259,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 7 ? "conv_h2q" : v.math == 6 ? "conv_h2w" : v.math == 5 ? "conv_h2p" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 8 ? "conv_h2r" : v.math == 7 ? "conv_h2q" : v.math == 6 ? "conv_h2w" : v.math == 5 ? "conv_h2p" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }
