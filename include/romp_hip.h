@@ -37,7 +37,7 @@ extern "C" {
 #define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
 #define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
 
-#define ROMP_ABI_VERSION 3
+#define ROMP_ABI_VERSION 4
 
 int         romp_abi_version(void);
 const char* romp_last_error(void);
@@ -161,6 +161,13 @@ int  romp_net_plan_info(romp_net* net, int32_t* input_size, int64_t* center_floa
  * median of `iters` passes. */
 int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,
                       float* params_maps_nhwc, void* stream, float* ms_out_host, int iters);
+/* Activation range scan (f16x2 range safety): runs the program op by op on `stream` and reports, for every op that writes an
+ * arena buffer, max|x| (maxabs_out_host[n_ops]; H2 tensors decoded) and the number of non-finite values
+ * (nonfinite_out_host[n_ops]) of that buffer's B images right after the op; 0 for ops without an arena output.  The host
+ * (plan.assign_formats) keeps tensors whose range does not fit the fp16 pieces of ROMP_FMT_H2 in float32 and their consumers on
+ * the f32 / bf16x3 kernels; the kernels themselves saturate at +-65504 instead of producing inf / NaN pieces.  Synchronises. */
+int  romp_net_range_scan(romp_net* net, const float* image_nhwc, int B, float* center_maps, float* params_maps_nhwc,
+                         void* stream, float* maxabs_out_host, int32_t* nonfinite_out_host);
 void romp_net_destroy(romp_net* net);
 
 /* Stand-alone conv launcher (tests / microbenchmarks of one layer).  variant < 0: heuristic. */

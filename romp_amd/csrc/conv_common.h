@@ -53,9 +53,14 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 // strides / offsets (multiples of 8) and every address computation are those of the float32 tensor.  Consumers copy the
 // units to LDS as they are (no conversion work, and they can be moved by LDS-DMA); producers split once in their
 // epilogue; residual adds and fuse sums use h1 + h2 (22 significant bits: 2^-23 relative, f32 rounding class).
+// Range: |x * 2^act_shift| beyond fp16's largest finite value SATURATES at +-65504 (v_med3: two VALU per value) instead of
+// turning the high piece into inf and the low piece into NaN; which tensors may be H2 at all is decided from measured
+// activation ranges (plan.assign_formats, romp_net_range_scan), the clamp is what keeps an unforeseen outlier finite.
+constexpr float H2_MAX = 65504.f;
+__device__ __forceinline__ float h2_sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, -H2_MAX), H2_MAX); }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo) {
-    const float x[4] = {v.x * act_scale, v.y * act_scale, v.z * act_scale, v.w * act_scale};
+    const float x[4] = {h2_sat(v.x * act_scale), h2_sat(v.y * act_scale), h2_sat(v.z * act_scale), h2_sat(v.w * act_scale)};
     f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

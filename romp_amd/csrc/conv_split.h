@@ -54,6 +54,7 @@ template <> struct Piece<3> {
 template <> struct Piece<2> {
     using frag = f16x8;
     static __device__ __forceinline__ void split(float x, unsigned short (&h)[2]) {
+        x = h2_sat(x);                                         // saturate instead of inf / NaN pieces (conv_common.h)
         const _Float16 h1 = (_Float16)x;                       // round to nearest even
         const float r1 = x - (float)h1;                        // exact
         const _Float16 h2 = (_Float16)r1;

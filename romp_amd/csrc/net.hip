@@ -7,6 +7,7 @@
 // caller's stream -- eagerly, or from a hipGraph captured per (batch, output pointers; the stem runs eagerly in front of it) so that the
 // ~330 dependent launches of one forward cost one graph launch on the host.
 #include "common.h"
+#include "conv_common.h"   // h2_unpack (range scan)
 #include <algorithm>
 #include <vector>
 #include <map>
@@ -497,6 +498,80 @@ int romp_net_profile(romp_net* n, const float* image, int B, float* center, floa
         if (v.empty()) { ms_out[i] = 0.f; continue; }
         std::sort(v.begin(), v.end());
         ms_out[i] = v.size() & 1 ? v[v.size() / 2] : 0.5f * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+    }
+    return rc;
+}
+
+// ---- activation range scan -----------------------------------------------------------------------------------------
+// max |x| and the number of non-finite values of a tensor region; H2 regions are decoded (h1 + h2) * 2^-shift per channel
+// octet (an octet = 32 bytes: eight high then eight low fp16 pieces).  One atomicMax on the float's bit pattern per wave.
+__global__ void range_scan_kernel(const float* x, size_t n, int h2, float inv_scale, unsigned* out_max, unsigned* out_bad) {
+    float m = 0.f;
+    unsigned bad = 0;
+    if (h2) {
+        const size_t n_oct = n >> 3;
+        for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n_oct; o += (size_t)gridDim.x * blockDim.x) {
+            const uint4 hi = *reinterpret_cast<const uint4*>(x + o * 8), lo = *reinterpret_cast<const uint4*>(x + o * 8 + 4);
+            const float4 a = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), inv_scale);
+            const float4 b = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), inv_scale);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (__builtin_isfinite(v[e])) m = fmaxf(m, fabsf(v[e])); else ++bad;
+            }
+        }
+    } else {
+        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+            const float v = x[i];
+            if (__builtin_isfinite(v)) m = fmaxf(m, fabsf(v)); else ++bad;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off));
+        bad += __shfl_xor(bad, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(out_max, __float_as_uint(m));                // m >= 0: the bit patterns order like the values
+        if (bad) atomicAdd(out_bad, bad);
+    }
+}
+
+// Runs the program op by op (one stream, the variants of romp_net_autotune if it ran) and reports for every op that writes an
+// arena buffer the max |x| / non-finite count of that buffer's B images right after the op (a buffer shared by several live
+// ranges may still hold part of an older tensor: the figure is an upper bound).  plan.assign_formats uses it to keep tensors
+// whose range does not fit the fp16 pieces of the H2 format in float32 and their consumers on the f32 / bf16x3 kernels.
+int romp_net_range_scan(romp_net* n, const float* image, int B, float* center, float* params, void* stream,
+                        float* maxabs_out_host, int32_t* nonfinite_out_host) {
+    ROMP_REQUIRE(n && image && center && params && maxabs_out_host && nonfinite_out_host && B > 0, "romp_net_range_scan: bad arguments");
+    if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nops = n->ops.size();
+    unsigned* d = nullptr;
+    ROMP_HIP_CHECK(hipMalloc((void**)&d, 2 * nops * sizeof(unsigned)));
+    int rc = ROMP_OK;
+    if (hipMemsetAsync(d, 0, 2 * nops * sizeof(unsigned), st) != hipSuccess) { set_error("hipMemsetAsync failed"); rc = ROMP_EHIP; }
+    const std::vector<int>* tv = tuned_for(n, B);
+    if (rc == ROMP_OK) rc = reset_queues(n, st);
+    for (size_t i = 0; i < nops && rc == ROMP_OK; ++i) {
+        rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, st);
+        const romp_op& op = n->ops[i];
+        if (rc || op.out_buf < 0 || op.out_buf >= (int)n->bufs.size() || op.kind == ROMP_OP_FORK || op.kind == ROMP_OP_JOIN) continue;
+        const size_t cnt = (size_t)n->buf_floats[op.out_buf] * B;
+        const int h2 = op.out_fmt == ROMP_FMT_H2;
+        hipLaunchKernelGGL(range_scan_kernel, dim3(1024), dim3(256), 0, st, n->bufs[op.out_buf], cnt, h2, ldexpf(1.f, -op.act_shift),
+                           d + i, d + nops + i);
+        if (hipGetLastError() != hipSuccess) { set_error("range_scan_kernel launch failed"); rc = ROMP_EHIP; }
+    }
+    std::vector<unsigned> h(2 * nops, 0u);
+    if (rc == ROMP_OK && hipMemcpyAsync(h.data(), d, 2 * nops * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("hipMemcpyAsync failed"); rc = ROMP_EHIP; }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == ROMP_OK) { set_error("hipStreamSynchronize failed"); rc = ROMP_EHIP; }
+    hipFree(d);
+    for (size_t i = 0; i < nops; ++i) {
+        float f;
+        memcpy(&f, &h[i], sizeof(float));
+        maxabs_out_host[i] = f;
+        nonfinite_out_host[i] = (int32_t)h[nops + i];
     }
     return rc;
 }

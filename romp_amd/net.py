@@ -6,6 +6,7 @@ params_maps (B,145,64,64)``.  PyTorch-ROCm owns the I/O tensors; all arithmetic 
 libromp_hip.so (csrc/conv_mfma.hip, stem_fuse.hip, net.hip).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -13,15 +14,21 @@ from . import lib as L
 from .plan import Program, build_romp_hrnet32, coord_channels, decode_h2, encode_h2
 
 
+_CHECK_FINITE = os.environ.get('ROMP_CHECK_FINITE', '0') not in ('', '0')
+
+
 class RompNet:
     def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
-                 out_shapes=None, bf16x3=False, split_k=None):
+                 out_shapes=None, bf16x3=False, split_k=None, calibrate=None, calib_images=None):
         """`builder(state_dict, device, input_size, bf16x3=) -> Program` (default: ROMP HRNet-32 + head);
         `out_shapes`: per-image shapes of the two output tensors of the program.  `bf16x3` is the conv_math
         setting: False / 'f32', True / 'bf16x3', 'f16x2' or 'all' (plan.set_conv_math).  `split_k`: lower the layers with few
         pixels and many input channels as split-K convs (plan.Program.conv); default: only for single-image nets
         (max_batch <= 2), where those layers are a handful of work items with a long serial channel loop; an int sets the
-        work-item target (default 128)."""
+        work-item target (default 128).  `calibrate` (default: whenever the f16x2 kernels are on offer): measure every
+        tensor's max|x| with a float32 forward of `calib_images` ((B,S,S,3) float 0..255 on the device; default: synthetic
+        frames) and keep tensors / layers whose range does not fit the fp16 pieces on the float32 path (plan.assign_formats,
+        `self.range_fallback` lists them); False skips it (ranges are then trusted to fit, the kernels only saturate)."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
@@ -35,10 +42,18 @@ class RompNet:
             self.split_k = (128 if self.max_batch <= 2 else 0) if split_k is None else (128 if split_k is True else int(split_k))
             kw = dict(split_k_items=self.split_k) if self.split_k else {}
             if builder is None:
-                self.program: Program = build_romp_hrnet32(state_dict, self.device, input_size, bf16x3=bf16x3, **kw)
-            else:
-                self.program = builder(state_dict, self.device, input_size, bf16x3=bf16x3, **kw)
+                builder = build_romp_hrnet32
+            self.program: Program = builder(state_dict, self.device, input_size, bf16x3=bf16x3, **kw)
+            if calibrate is None:
+                calibrate = bool(getattr(self.program, 'f16x2', False))
+            self.op_maxabs = None
+            if calibrate:
+                ms = input_size // 8
+                self.op_maxabs = self._measure_ranges(state_dict, builder, kw, input_size, out_shapes or ((ms, ms), (ms, ms, 145)),
+                                                      calib_images)
+                self.program.op_maxabs = self.op_maxabs
             ops = self.program.op_array()
+            self.range_fallback = list(getattr(self.program, 'range_fallback', []))
             sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
             h = C.c_void_p()
             L.check(self.lib.romp_net_create(C.byref(h), ops, len(self.program.ops), sizes,
@@ -56,6 +71,46 @@ class RompNet:
             torch.cuda.synchronize(self.device)
         if use_graph:
             self.set_graph(True)
+
+    def _measure_ranges(self, state_dict, builder, kw, input_size, out_shapes, calib_images):
+        """max|x| per op output of the same program lowered with conv_math='f32' (every tensor float32, exact-f32 kernels), over
+        a few calibration frames -> list aligned with self.program.ops (None where an op writes no arena buffer)."""
+        import math
+        P32 = builder(state_dict, self.device, input_size, bf16x3='f32', **kw)
+        assert len(P32.ops) == len(self.program.ops) and all(a.kind == b.kind for a, b in zip(P32.ops, self.program.ops)), \
+            'the float32 lowering must have the same op list'
+        if calib_images is None:
+            g = torch.Generator(device='cpu').manual_seed(20240924)
+            lin = torch.linspace(0, 255, input_size)
+            calib_images = torch.stack([
+                torch.rand(input_size, input_size, 3, generator=g) * 255.0,                      # white noise
+                (lin[:, None, None] * 0.5 + lin[None, :, None] * 0.5).expand(-1, -1, 3).clone(),   # smooth ramp
+                (torch.rand(input_size // 16, input_size // 16, 3, generator=g) * 255.0).repeat_interleave(16, 0).repeat_interleave(16, 1),
+            ]).to(self.device)
+        calib_images = calib_images.to(self.device, torch.float32).contiguous()
+        B = min(int(calib_images.shape[0]), 4)
+        ops32 = P32.op_array()
+        sizes = (C.c_int64 * len(P32.buf_floats))(*P32.buf_floats)
+        h = C.c_void_p()
+        L.check(self.lib.romp_net_create(C.byref(h), ops32, len(P32.ops), sizes, len(P32.buf_floats), B))
+        try:
+            if P32.coord_off is not None:
+                coords = coord_channels(B, input_size // 4, self.device, P32.head_in_ch, P32.coord_off)
+                L.check(self.lib.romp_net_write_buffer(h, P32.head_in_buf, L.ptr(coords), coords.numel(), L.stream_ptr(self.device)))
+            c = torch.empty((B,) + tuple(out_shapes[0]), device=self.device)
+            q = torch.empty((B,) + tuple(out_shapes[1]), device=self.device)
+            mx = (C.c_float * len(P32.ops))()
+            bad = (C.c_int32 * len(P32.ops))()
+            L.check(self.lib.romp_net_range_scan(h, L.ptr(calib_images[:B]), B, L.ptr(c), L.ptr(q), L.stream_ptr(self.device), mx, bad))
+        finally:
+            self.lib.romp_net_destroy(h)
+        out = []
+        for i, op in enumerate(P32.ops):
+            if op.out_buf < 0 or op.kind in (L.OP_FORK, L.OP_JOIN):
+                out.append(None)
+            else:
+                out.append(math.inf if bad[i] else float(mx[i]))
+        return out
 
     @classmethod
     def from_plan(cls, path, device, max_batch=32, use_graph=False, out_shapes=None):
@@ -131,6 +186,10 @@ class RompNet:
             params_out = torch.empty((B,) + tuple(self.out_shapes[1]), device=self.device, dtype=torch.float32)
         L.check(self.lib.romp_net_forward(self._h, L.ptr(image), B, L.ptr(center_out), L.ptr(params_out),
                                           L.stream_ptr(self.device)))
+        if _CHECK_FINITE:                                     # debug mode (env ROMP_CHECK_FINITE=1): one reduction + sync per forward
+            if not (bool(torch.isfinite(center_out).all()) and bool(torch.isfinite(params_out).all())):
+                raise L.RompHipError('non-finite values in the network outputs (activation range outside the f16x2 kernels\' '
+                                     'fp16 pieces? build the net with calibrate=True / conv_math=\'f32\')')
         return center_out, params_out
 
     def __call__(self, image):

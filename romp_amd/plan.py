@@ -116,6 +116,18 @@ def pack_conv_weight_h2(w, cin_pad, cout_pad):
 
 
 ACT_SHIFT = 4            # f16x2 kernels: activations are split as fp16 pieces of 16*x (|x| < 4094)
+# Range of max|x| over a tensor for which the fp16 pieces of x * 2^ACT_SHIFT are as good as float32 (DESIGN.md section 4,
+# "range safety"): above H2_HI the high piece would leave fp16 (the kernels saturate at 65504 = 4094 * 16; the limit keeps a
+# factor two of head-room over the calibration data), below H2_LO most high pieces are fp16 subnormals and the pair holds fewer
+# than 22 bits relative to the tensor's largest values.  assign_formats keeps tensors outside it in float32 and takes the f16x2
+# weights away from their consumers (they run on the f32 / bf16x3 kernels).
+H2_HI = 2.0 ** (15 - ACT_SHIFT)
+H2_LO = 2.0 ** (-2 - ACT_SHIFT)
+
+
+def h2_range_ok(maxabs):
+    """May a tensor whose largest magnitude is `maxabs` (None: not measured) be split into fp16 pieces of x * 2^ACT_SHIFT?"""
+    return maxabs is None or maxabs == 0.0 or (H2_LO <= maxabs < H2_HI)
 
 
 def set_conv_math(P, conv_math):
@@ -155,9 +167,11 @@ def assign_formats(P):
     H2 (vector-epilogue convs, stem, fuse sums) and every consumer reads it through an f16x2 kernel or a fuse sum; tensors
     touched by anything else (max-pool, BEV head pieces, Conv1d, the host through romp_net_buffer_ptr) stay float32."""
     P.buf_fmt = {}                                           # buffer -> format of its LAST live range (for read_buffer)
+    P.range_fallback = []                                    # (op index, name, max|x|): ops taken off the f16x2 kernels
     if not getattr(P, 'f16x2', False):
         return
     gens, cur = [], {}
+    maxabs = getattr(P, 'op_maxabs', None)                   # per op: max|x| of its output (RompNet.calibrate), or None
 
     def gen_for_write(buf):
         g = cur.get(buf)
@@ -224,6 +238,18 @@ def assign_formats(P):
                 if b >= 0:
                     gen_for_write(b)['ok'] = False
     for g in gens:
+        if maxabs is not None:                               # range safety: measured max|x| of the tensor's producers
+            ms = [maxabs[i] for i, r in g['uses'] if r == 'out' and maxabs[i] is not None]
+            if not any(r == 'out' for _, r in g['uses']):    # initialised from outside the program: the host may state its range
+                ms = [v for v in [getattr(P, 'buf_maxabs', {}).get(g['buf'])] if v is not None]
+            m = max(ms) if ms else None
+            if not h2_range_ok(m):
+                g['ok'] = False
+                for i, r in g['uses']:
+                    if r == 'in' and P.ops[i].kind == OP_CONV and P.ops[i].weight_h2:
+                        # an f16x2 kernel would split this float32 tensor in registers with the same 2^ACT_SHIFT: not this op
+                        P.ops[i].weight_h2, P.ops[i].scale_h2 = 0, 0
+                        P.range_fallback.append((i, P.names[i] if i < len(P.names) else 'op%d' % i, m))
         fmt = FMT_H2 if (g['ok'] and any(r == 'out' for _, r in g['uses'])) else FMT_F32
         P.buf_fmt[g['buf']] = fmt
         for i, role in g['uses']:

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), 'libromp_hip.so does not export %s' % n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert h.romp_abi_version() == L.ABI_VERSION == 3
+    assert h.romp_abi_version() == L.ABI_VERSION == 4
 
 
 def test_romp_op_struct_layout_matches_header():
@@ -294,6 +294,41 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             if op.out_buf >= 0:
                 written[op.out_buf] = L.FMT_F32
     assert n_h2 > 50, n_h2
+
+
+def test_range_guard_moves_out_of_range_tensors_to_float32():
+    """f16x2 range safety (plan.assign_formats + RompNet calibration): given measured max|x| per op output, a tensor outside
+    [H2_LO, H2_HI) is stored as float32, its consumer convs lose their f16x2 weights (and still have a kernel), everything
+    else keeps the H2 format; without measurements nothing changes."""
+    from romp_amd import lib as L, synthetic as S
+    from romp_amd.plan import build_romp_hrnet32, h2_range_ok, H2_HI, H2_LO
+    assert h2_range_ok(None) and h2_range_ok(0.0) and h2_range_ok(1.0) and h2_range_ok(H2_LO) and not h2_range_ok(H2_HI)
+    assert not h2_range_ok(1e4) and not h2_range_ok(1e-6) and not h2_range_ok(float('inf'))
+    h = L.load()
+    sd = S.make_romp_state_dict(0)
+    base = build_romp_hrnet32(sd, 'cpu', 512, bf16x3='f16x2')
+    base.op_array()
+    assert base.range_fallback == []
+    conv_ids = [i for i, o in enumerate(base.ops) if o.kind == L.OP_CONV and o.out_fmt == L.FMT_H2 and o.out_buf >= 0]
+    victim = conv_ids[len(conv_ids) // 2]
+    P = build_romp_hrnet32(sd, 'cpu', 512, bf16x3='f16x2')
+    P.op_maxabs = [1.0 if (o.out_buf >= 0 and o.kind not in (L.OP_FORK, L.OP_JOIN)) else None for o in P.ops]
+    P.op_maxabs[victim] = 3.0e4
+    P.op_array()
+    assert P.ops[victim].out_fmt == L.FMT_F32 and base.ops[victim].out_fmt == L.FMT_H2
+    hit = [i for i, _, m in P.range_fallback]
+    assert hit and all(m == 3.0e4 for _, _, m in P.range_fallback)
+    buf = C.create_string_buffer(128)
+    for i in hit:
+        op = P.ops[i]
+        assert op.in_buf == P.ops[victim].out_buf and op.in_fmt == L.FMT_F32 and not op.weight_h2
+        valid = [v for v in range(h.romp_conv_num_variants()) if h.romp_conv_describe(C.byref(op), 32, v, buf, 128) == 0]
+        assert valid, 'no kernel left for %s' % P.names[i]
+        for v in valid:
+            h.romp_conv_describe(C.byref(op), 32, v, buf, 128)
+            assert b'h2' not in buf.value
+    same = sum(a.out_fmt == b.out_fmt and a.in_fmt == b.in_fmt for a, b in zip(P.ops, base.ops))
+    assert same >= len(P.ops) - len(hit) - 4          # only the victim's live range changes
 
 
 def test_plan_file_roundtrip_on_host(tmp_path):

@@ -237,6 +237,105 @@ def test_conv_layer(dev, case, B, fmt):
         assert err < 3e-5, f'{name} err {err}'
 
 
+@pytest.mark.parametrize('mag', [1e4, 1e-6])
+@pytest.mark.parametrize('case', [(32, 32, 3, 1, 64, True, True), (64, 128, 3, 2, 64, False, False), (64, 64, 1, 1, 64, True, False)],
+                         ids=lambda c: 'c%d_%d_k%d_s%d' % c[:4])
+def test_conv_layer_range_guard(dev, case, mag):
+    """f16x2 range safety: a layer whose input is 1e4x / 1e-6x the usual magnitude.  With the measured range
+    handed to plan.assign_formats the layer leaves the f16x2 kernels (float32 tensors, f32 / bf16x3 kernels) and EVERY variant
+    still on offer meets the usual 3e-5 bound relative to the output's magnitude; without it the f16x2 kernels saturate at
+    65504 / 2^shift -- finite garbage for the large input, never inf / NaN."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math, h2_range_ok
+    cin, cout, k, s, H, relu, use_res = case
+    g = torch.Generator().manual_seed(7 + cin + cout + k)
+    x = torch.randn(2, H, H, cin, generator=g) * mag
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1 * mag
+    Ho = (H + 2 * (k // 2) - k) // s + 1
+    res = torch.randn(2, Ho, Ho, cout, generator=g) * mag if use_res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride=s, padding=k // 2)
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.permute(0, 2, 3, 1).float()
+    assert not h2_range_ok(float(x.abs().max()))
+    lib = L.load()
+    buf = C.create_string_buffer(128)
+
+    def lower(guard):
+        P = Program(dev)
+        set_conv_math(P, 'all')
+        P.buf_floats.append(cin * H * H)
+        ra = None
+        if res is not None:
+            P.buf_floats.append(cout * Ho * Ho)
+            ra = Act(1, cout, Ho, Ho, cout)
+        P.conv('t', Act(0, cin, H, H, cin), [w], [scale], [shift], k, s, relu, res=ra)
+        if guard:
+            P.op_maxabs = [None] * len(P.ops)
+            P.buf_maxabs = {0: float(x.abs().max())}
+        P.op_array()                                     # assign_formats
+        P.ops[0].out_fmt = L.FMT_F32                     # (nothing consumes the output here: read it back as plain floats)
+        return P, P.ops[0]
+
+    xd, rd = x.to(dev), (res.to(dev) if res is not None else None)
+    P, op = lower(True)
+    assert not op.weight_h2 and len(P.range_fallback) == 1, 'the guard must take the f16x2 weights away'
+    runs = [-1] + [v for v in range(lib.romp_conv_num_variants()) if lib.romp_conv_describe(C.byref(op), 2, v, buf, 128) == 0]
+    assert len(runs) >= 2
+    for v in runs:
+        out = torch.full((2, Ho, Ho, cout), float('nan'), device=dev)
+        L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), L.ptr(rd), L.ptr(out), 2, 0, v, L.stream_ptr(dev)))
+        L.check(lib.romp_conv_describe(C.byref(op), 2, v, buf, 128))
+        assert b'h2' not in buf.value, buf.value
+        err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f'{buf.value.decode()} (variant {v}) x{mag:g}: relative err {err:.3e}')
+        assert err < 3e-5, (buf.value, err)
+    # without the guard: the f16x2 kernels stay on offer and must at least stay finite
+    P2, op2 = lower(False)
+    assert op2.weight_h2
+    for v in range(lib.romp_conv_num_variants()):
+        if lib.romp_conv_describe(C.byref(op2), 2, v, buf, 128) != 0 or b'h2' not in buf.value:
+            continue
+        out = torch.full((2, Ho, Ho, cout), float('nan'), device=dev)
+        L.check(lib.romp_conv_forward(C.byref(op2), L.ptr(xd), L.ptr(rd), L.ptr(out), 2, 0, v, L.stream_ptr(dev)))
+        assert bool(torch.isfinite(out).all()), '%s produced inf / NaN' % buf.value.decode()
+
+
+def test_net_range_calibration(dev):
+    """Whole net with activations far outside the fp16 pieces' range (the stem's BatchNorm scaled so that everything downstream
+    is ~3e3 x larger): RompNet's calibration moves the affected tensors / layers to the float32 path (range_fallback), the maps
+    stay finite and agree with the exact-f32 net to 1e-4 of their magnitude; without calibration the f16x2 net saturates but
+    stays finite (the kernels clamp), and ROMP_CHECK_FINITE-style checking passes.  With the ordinary weights nothing falls back."""
+    from romp_amd.net import RompNet
+    sd = O.make_romp_state_dict(0)
+    img = O.make_images(2, seed=3).to(dev)
+    net_ok = RompNet(sd, dev, max_batch=2, bf16x3='f16x2')
+    assert net_ok.op_maxabs is not None and net_ok.range_fallback == [], net_ok.range_fallback
+    big = {k: v.clone() for k, v in sd.items()}
+    key_w = [k for k in big if k.endswith('bn2.weight') and k.count('.') <= 2][0]
+    big[key_w] *= 3e3
+    big[key_w.replace('weight', 'bias')] *= 3e3
+    ref = RompNet(big, dev, max_batch=2, bf16x3='f32')
+    cm_r, pm_r = ref(img)
+    mag = max(cm_r.abs().max().item(), pm_r.abs().max().item())
+    assert mag > 50.0, 'the scaled stem must blow the activations up (%g)' % mag
+    net = RompNet(big, dev, max_batch=2, bf16x3='f16x2')
+    assert len(net.range_fallback) > 10, 'calibration must flag the blown-up layers'
+    cm, pm = net(img)
+    assert bool(torch.isfinite(cm).all()) and bool(torch.isfinite(pm).all())
+    e = max((cm - cm_r).abs().max().item(), (pm - pm_r).abs().max().item()) / mag
+    print(f'{len(net.range_fallback)} layers on the float32 path, maps relative err {e:.3e} (magnitude {mag:.3g})')
+    assert e < 1e-4
+    raw = RompNet(big, dev, max_batch=2, bf16x3='f16x2', calibrate=False)
+    cm2, pm2 = raw(img)
+    assert bool(torch.isfinite(cm2).all()) and bool(torch.isfinite(pm2).all()), 'saturation, not inf / NaN'
+
+
 def test_fusesum_formats(dev):
     """The fuse sum (model.py:233-244) with float32 and H2 terms / outputs gives the same values (the power-of-two scaling of
     the H2 format commutes with every rounding of the sum)."""
