@@ -38,7 +38,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf
 BX3_PRODUCTS = 6                  # bf16 piece products issued per f32 product by the bf16x3 kernels
 H2_PRODUCTS = 3                   # fp16 piece products issued per f32 product by the f16x2 kernels
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = 'r02'               # profiles/<tag>_pmc_*_by_kernel.csv: the committed rocprofv3 PMC passes of this build
+PROFILE_TAG = 'r03'               # profiles/<tag>_pmc_traffic_by_op.json: the committed rocprofv3 PMC passes of this build
 
 
 def parse_args():
@@ -61,7 +61,12 @@ def parse_args():
     ap.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],
                     help='resnet50: BASELINE configs[0]\'s model (the reference runs it on the CPU only) at the headline batch size')
     ap.add_argument('--tune-file', type=str, default=None,
-                    help='JSON cache of the autotuned variant table: loaded if it exists (no measuring launches), else written')
+                    help='kernel-variant table by name (romp_amd/tuning.py): installed if it exists (no measuring launches), else '
+                         'written after autotuning.  Default: the committed table of this configuration under romp_amd/tune/, '
+                         'if there is one; "none": always autotune')
+    ap.add_argument('--dump-op-kernels', type=str, default=None,
+                    help='write the per-op kernel names / algorithmic bytes of the batch to this JSON (scripts/summarize_pmc.py aligns '
+                         'rocprofv3 dispatches with ops through it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline sample')
     ap.add_argument('--no-roofline', action='store_true')
@@ -76,12 +81,12 @@ def parse_args():
 # ------------------------------------------------------------------------------------------------ roofline
 def kernel_of(variant_name):
     import re
-    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
     fam, ks, s, mt, nt, tw, ck = m.groups()
-    if fam == 'h2q':
-        return 'conv_h2q_kernel<%s, %s, %s>' % (mt, nt, tw)
+    if fam in ('h2q', 'h2r'):
+        return 'conv_%s_kernel<%s, %s, %s>' % (fam, mt, nt, tw)
     if fam in ('h2p', 'h2w'):
         return 'conv_h2p_kernel<%s, %s, %s, %s>' % (mt, nt, tw, 'true' if fam == 'h2w' else 'false')
     if fam in ('h2o', 'h2do'):
@@ -89,27 +94,23 @@ def kernel_of(variant_name):
     return 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % (fam, ks, s, mt, nt, tw, ck)
 
 
-def pmc_traffic(variant_name, pmc_dir, workload=''):
-    """HBM bytes per launch of the kernel behind `variant_name` from the committed rocprofv3 PMC passes
-    (profiles/<tag>_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv, produced by scripts/gpu_profile.sh: separate --pmc passes of
-    this same command; unit KiB per dispatch; FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).
-    None if the files or the kernel are missing -- PMC counters cannot be read from inside this process, and a stale
-    file (kernel no longer in the variant table) must not be quoted."""
-    import csv
-    kern = kernel_of(variant_name)
-    if kern is None:
+def pmc_traffic(op_ids, op_names, pmc_dir, workload=''):
+    """Measured HBM bytes per launch over the op index set `op_ids`, from the committed rocprofv3 --pmc passes of this same
+    command (profiles/<tag><workload>_pmc_traffic_by_op.json, written by scripts/summarize_pmc.py --by-op from separate
+    FETCH_SIZE / WRITE_SIZE passes: per op index the mean over the profiled forwards of 2 * FETCH_SIZE + WRITE_SIZE, the
+    gfx950 correction of MI355X_MICROARCH.md).  The file records the kernel name each op ran as; a mismatch with this run
+    (a different variant table) means the counters are about other kernels: None, never a stale quote."""
+    path = os.path.join(pmc_dir, '%s%s_pmc_traffic_by_op.json' % (PROFILE_TAG, workload))
+    if not os.path.exists(path):
         return None
-    vals = {}
-    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
-        path = os.path.join(pmc_dir, '%s%s_pmc_%s_by_kernel.csv' % (PROFILE_TAG, workload, counter))
-        if not os.path.exists(path):
+    t = json.load(open(path))
+    tot = 0.0
+    for i in op_ids:
+        e = t['ops'].get(str(i))
+        if e is None or e['kernel'] != op_names[i]:
             return None
-        for row in csv.DictReader(open(path)):
-            if kern in row['kernel']:
-                vals[counter] = float(row[counter + '_mean']) * 1024.0
-    if len(vals) != 2:
-        return None
-    return dict(bytes=2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'], kernel=kern)
+        tot += e['bytes']
+    return dict(bytes=tot / max(1, len(op_ids)), source=os.path.relpath(path, ROOT))
 
 
 def roofline_report(net, images, pmc_workload=None):
@@ -118,11 +119,12 @@ def roofline_report(net, images, pmc_workload=None):
     B = images.shape[0]
     ms = net.profile(images, iters=3)
     agg = {}
-    for name, t, fl, by in zip(net.variant_names(B), ms, net.program.flops, net.program.bytes):
+    op_names = net.variant_names(B)
+    for i, (name, t, fl, by) in enumerate(zip(op_names, ms, net.program.flops, net.program.bytes)):
         if name in ('fork', 'join'):
             continue
-        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        a['ms'] += t; a['flops'] += fl * B; a['bytes'] += by * B; a['launches'] += 1
+        a = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, ops=[]))
+        a['ms'] += t; a['flops'] += fl * B; a['bytes'] += by * B; a['launches'] += 1; a['ops'].append(i)
     classes = {}
     for k, a in agg.items():
         classes[k] = dict(launches=a['launches'], ms=round(a['ms'], 4),
@@ -156,13 +158,15 @@ def roofline_report(net, images, pmc_workload=None):
     # DEFAULT workload (profiles/README.md) and is reported only for that workload (a kernel name alone does not identify the
     # layers behind it: the ResNet-50 / BEV / other-batch lines carry null) and only if the dominant kernel is in those passes
     # pmc_workload: '' = the default workload, '_resnet50' / '_bev' = their own passes, None = no passes for this configuration
-    t = pmc_traffic(name, os.path.join(ROOT, 'profiles'), pmc_workload) if pmc_workload is not None else None
-    if pmc_workload is None:
-        roof['traffic_note'] = 'null: no committed PMC passes (profiles/%s*_pmc_*) for this configuration' % PROFILE_TAG
-    if t is not None:                        # measured in a separate rocprofv3 --pmc pass of this command (profiles/README.md)
+    t = pmc_traffic(a['ops'], op_names, os.path.join(ROOT, 'profiles'), pmc_workload) if pmc_workload is not None else None
+    if t is None:
+        roof['traffic_note'] = ('null: no committed PMC passes (profiles/%s*_pmc_traffic_by_op.json) for this configuration, or they were '
+                                'taken with another kernel-variant table' % PROFILE_TAG)
+    else:                                    # measured in separate rocprofv3 --pmc passes of this command, same variant table
         roof['traffic'] = round(t['bytes'])
-        roof['traffic_source'] = 'profiles/%s%s_pmc_{FETCH,WRITE}_SIZE_by_kernel.csv: 2*FETCH_SIZE + WRITE_SIZE of %s, mean per dispatch' % (PROFILE_TAG, pmc_workload, t['kernel'])
+        roof['traffic_source'] = '%s: mean of 2*FETCH_SIZE + WRITE_SIZE over exactly the %d ops of this kernel class' % (t['source'], len(a['ops']))
         roof['traffic_over_algorithmic'] = round(t['bytes'] / (a['bytes'] / a['launches']), 3)
+    roof['op_ids'] = a['ops']
     return roof, classes
 
 
@@ -195,18 +199,26 @@ def usable_cores():
 
 # ------------------------------------------------------------------------------------------------ CPU baseline / parity
 def cpu_baseline(sd, smpl_model, thresh, seconds):
-    """The oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
-    from oracle import romp_oracle as O
+    """The reference's CPU path on a bounded sample of the same workload, on this box's host cores: the REFERENCE ITSELF
+    (ROMPv1 + parsing_outputs + SMPL of simple_romp/romp, run from oracle/_ref/romp/*.pyc, kind "reference") when
+    oracle/Makefile staged it, else the oracle restatement (kind "port")."""
+    from oracle import romp_oracle as O, ref_cpu
     from romp_amd import synthetic as S
     torch.set_num_threads(usable_cores())
     Bc = 4
     img = S.make_images(Bc, seed=1)
+    kind = 'reference' if ref_cpu.available() else 'port'
+    if kind == 'reference':
+        pipe = ref_cpu.ReferencePipeline(sd, smpl_model, thresh)
 
-    def step():
-        cm, pm = O.romp_net_forward(sd, img)
-        r = O.parsing_outputs(cm.numpy(), pm.numpy(), thresh)
-        if r is not None:
-            O.smpl_forward(smpl_model, r['smpl_betas'], r['smpl_thetas'])
+        def step():
+            pipe(img)
+    else:
+        def step():
+            cm, pm = O.romp_net_forward(sd, img)
+            r = O.parsing_outputs(cm.numpy(), pm.numpy(), thresh)
+            if r is not None:
+                O.smpl_forward(smpl_model, r['smpl_betas'], r['smpl_thetas'])
     t0 = time.time()
     step()                                    # warm-up (also bounds the sample on a slow host)
     warm = time.time() - t0
@@ -218,10 +230,13 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
     dt = time.time() - t0
     if n == 0:
         n, dt = 1, warm
-    return dict(value=round(Bc * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload: the oracle restatement of the reference on '
-                       'torch-CPU float32 (kind=port: /root/reference does not exist on the GPU box, and its onnxruntime path needs a module that '
-                       'is not installed)' % (n, Bc))
+    what = ('the reference itself: ROMPv1 (simple_romp/romp/model.py:420-481) + parsing_outputs (post_parser.py:135-146) + SMPL '
+            '(smpl.py:62-108), PyTorch-CPU float32, byte-compiled from /root/reference into oracle/_ref/romp (its onnxruntime '
+            'session, main.py:86-89, needs a module that is not installed: this is the --onnx=False path, main.py:74-77)'
+            if kind == 'reference' else
+            'the oracle restatement of the reference on torch-CPU float32 (oracle/_ref/romp is not staged on this box)')
+    return dict(value=round(Bc * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind=kind,
+                sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload: %s' % (n, Bc, what))
 
 
 def parity_report(model, images, sd, smpl_model, thresh, pick=(0, 17)):
@@ -259,30 +274,57 @@ def parity_report(model, images, sd, smpl_model, thresh, pick=(0, 17)):
 
 
 def end_to_end(model, lib, L, dev, batch, n_calls, stream):
-    """The same job starting from uint8 frames in (pinned) host memory: H2D of 0.79 MB/image + batched device pre-processing
-    (BGR->RGB, pad, cv::resize-exact INTER_CUBIC; csrc/post.hip) + net + parse + SMPL, all inside the timed region."""
+    """The same job starting from uint8 frames in pinned host memory: H2D of 0.79 MB/image + batched device pre-processing
+    (BGR->RGB, pad, cv::resize-exact INTER_CUBIC; csrc/post.hip) + net + parse + SMPL, all inside the timed region.  The upload of
+    call i+1 runs on a copy stream under the compute of call i (two pinned host buffers, two device frame buffers, events both
+    ways); `serial` is the same loop with the copy on the compute stream (round 2's figure)."""
     g = torch.Generator().manual_seed(11)
-    frames = torch.randint(0, 256, (batch, 512, 512, 3), generator=g, dtype=torch.uint8).pin_memory()
-    fdev = torch.empty(batch, 512, 512, 3, device=dev, dtype=torch.uint8)
+    frames = [torch.randint(0, 256, (batch, 512, 512, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    fdev = [torch.empty(batch, 512, 512, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
     x = torch.empty(batch, 512, 512, 3, device=dev, dtype=torch.float32)
     pad = (C.c_float * 6)()
+    copy_s = torch.cuda.Stream(dev)
+    copied = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
 
-    def call():
-        fdev.copy_(frames, non_blocking=True)
-        L.check(lib.romp_preprocess_batch(L.ptr(fdev), batch, 512, 512, L.ptr(x), 512, pad, L.stream_ptr(dev)))
-        return model.forward_batch(x)
-    with torch.cuda.stream(stream):
-        for _ in range(2):
-            call()
+    def upload(i, overlap):
+        k = i & 1
+        if overlap:
+            with torch.cuda.stream(copy_s):
+                copy_s.wait_event(consumed[k])               # the pre-processing that last read fdev[k] is done
+                fdev[k].copy_(frames[k], non_blocking=True)
+                copied[k].record(copy_s)
+        else:
+            fdev[k].copy_(frames[k], non_blocking=True)
+
+    def run(overlap):
+        for k in range(2):
+            consumed[k].record(torch.cuda.current_stream(dev))
+        if overlap:
+            upload(0, True)                                  # pipeline prologue; the loop below issues n_calls uploads as well
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(n_calls):
-            call()
+        for i in range(n_calls):
+            k = i & 1
+            if overlap:
+                upload(i + 1, True)                          # next call's frames: in flight under this call's network
+                torch.cuda.current_stream(dev).wait_event(copied[k])
+            else:
+                upload(i, False)
+            L.check(lib.romp_preprocess_batch(L.ptr(fdev[k]), batch, 512, 512, L.ptr(x), 512, pad, L.stream_ptr(dev)))
+            consumed[k].record(torch.cuda.current_stream(dev))
+            model.forward_batch(x)
         torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    with torch.cuda.stream(stream):
+        run(True)                                            # warm-up
+        dt = run(True)
+        dts = run(False)
     return dict(value=round(batch * n_calls / dt, 2), unit='images/s', ms_per_call=round(dt / n_calls * 1e3, 3), calls=n_calls,
-                includes='per call: H2D of %d uint8 512x512x3 frames from pinned host memory + device pre-processing + net + parse + SMPL '
-                         '(one stream, no copy/compute overlap)' % batch)
+                serial=dict(value=round(batch * n_calls / dts, 2), ms_per_call=round(dts / n_calls * 1e3, 3)),
+                includes='per call: H2D of %d uint8 512x512x3 frames from pinned host memory (copy stream, overlapped with the previous '
+                         "call's compute) + device pre-processing + net + parse + SMPL" % batch)
 
 
 def single_image_latency(sd, smpl_model, args, dev, stream, n=40):
@@ -386,12 +428,7 @@ def bench_bev(args, dev):
     model = bev.BEV(s, state_dict=sd, smpla_model=smpla, smil_model=smil)
     images = S.make_images(args.batch, seed=4, device=dev)
     net = model.model.net
-    if args.tune_file and os.path.exists(args.tune_file):
-        net.set_tuned(args.batch, json.load(open(args.tune_file))[str(args.batch)])
-    elif args.autotune:
-        net.autotune(args.batch)
-        if args.tune_file:
-            json.dump({str(args.batch): net.tuned_variants(args.batch)}, open(args.tune_file, 'w'))
+    variant_table = install_variants(args, net, args.batch, 0, 'bev-hrnet32', lambda m: print('bench.py: ' + m, file=sys.stderr, flush=True))
     pads = torch.tensor([[0., 512., 0., 512., 512., 512.]]).repeat(args.batch, 1)
     # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
     # ~12 persons per image, the load the ROMP line runs at
@@ -420,7 +457,7 @@ def bench_bev(args, dev):
            'vs_baseline': None, 'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (%s-split conv products)' % args.conv_math, 'data': 'synthetic',
            'config': {'workload': 'BEV HRNet-32 + BEV head 512x512 batch=%d (BASELINE configs[3]); net+3D parse+'
                                   'regression+SMPL-A+post-processing' % args.batch,
-                      'persons_kept_per_image': round(n / args.batch, 2), 'center_thresh': round(mid, 4)}}
+                      'persons_kept_per_image': round(n / args.batch, 2), 'center_thresh': round(mid, 4), 'variant_table': variant_table}}
     if not args.no_roofline:
         s1 = torch.cuda.Stream(dev)
         with torch.cuda.stream(s1):
@@ -454,8 +491,131 @@ def bench_bev(args, dev):
 
 
 # ------------------------------------------------------------------------------------------------ headline
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks of this same command under
+    torch.distributed.run on this node (rendezvous on 127.0.0.1) and hand back its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(step, warmup, steps, dev, world):
+    """The contract's timing discipline: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier and a device
+    synchronisation on both sides; the MAX over ranks is the job's time."""
+    sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == 'cuda' else (lambda: None)
+    for _ in range(warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def collective_info(world, dev):
+    """What the result line says about the fabric: ranks in the process group, backend, RCCL version."""
+    info = {'rccl_ranks': world, 'backend': 'none (single process)' if world == 1 else dist.get_backend()}
+    if world > 1:
+        assert dist.get_world_size() == world
+    if dev.type == 'cuda':
+        try:
+            v = torch.cuda.nccl.version()
+            info['rccl_version'] = '.'.join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception as e:                               # noqa: BLE001 -- informational only
+            info['rccl_version'] = 'unknown (%s)' % type(e).__name__
+    return info
+
+
+def run_job(args, model, images, lo, rank, world, dev, D):
+    """The timed job of the headline line: every rank walks its resident shard in calls of --batch images (net + parse + SMPL);
+    N > 1: one all-gather of the per-person records per step.  -> (seconds for args.steps steps (max over ranks), persons)."""
+    B = args.batch
+    persons = [0]
+
+    def step():
+        if world > 1:
+            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts), chunk=B)
+            persons[0] = sum(counts)
+        else:
+            rec = D.local_records(model, images, lo, chunk=B, with_joints=True, with_verts=bool(args.with_verts))
+            persons[0] = 0 if rec is None else rec.shape[0]
+    dt = timed_steps(step, args.warmup, args.steps, dev, world)
+    return dt, persons[0]
+
+
+def headline_result(args, dt, persons, G, n_local, world, dev, variant_table):
+    B = args.batch
+    strong = args.global_batch > 0
+    bb = 'HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'
+    if strong:
+        workload = ('ROMP %s 512x512, batch=%d synthetic images sharded across %d GPU%s (BASELINE configs[2]), each shard walked in forward calls of '
+                    'batch=%d (BASELINE configs[1]); net+parse+SMPL per call%s' %
+                    (bb, G, world, '' if world == 1 else 's', B, ', one RCCL all-gather of the per-person records per step' if world > 1 else ''))
+    else:
+        workload = 'ROMP %s 512x512, batch=%d synthetic images per GPU per step (weak scaling); net+parse+SMPL%s' % (
+            bb, B, '+RCCL all-gather of per-person records' if world > 1 else '')
+    cfg = {'workload': workload, 'batch_per_call': B, 'global_batch': G, 'images_per_gpu_per_step': n_local,
+           'ms_per_call': round(dt / args.steps / max(1, -(-n_local // B)) * 1e3, 3),
+           'persons_per_image': round(persons / G, 2), 'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph),
+           'autotune': bool(args.autotune), 'variant_table': variant_table, 'branch_streams': bool(args.streams),
+           'conv_math': args.conv_math, 'parallelism': 'dp%d' % world}
+    cfg.update(collective_info(world, dev))
+    return {
+        'metric': 'images/sec (512x512, %s)' % bb, 'value': round(G * args.steps / dt, 2), 'unit': 'images/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as %s-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)' % args.conv_math,
+        'data': 'synthetic', 'config': cfg,
+    }
+
+
+def install_variants(args, net, B, rank, backbone, log):
+    """One variant table for everything measured: the committed table of this configuration (or --tune-file) if it resolves
+    against this build, else autotune (and say so).  -> the string reported as config.variant_table."""
+    from romp_amd import tuning as T
+    path = args.tune_file
+    if path is None:
+        path = T.default_table_path(backbone, args.conv_math, B)
+        committed = True
+    else:
+        committed = False
+    if path and path != 'none':
+        ok, why = T.install_table(net, B, path)
+        if ok:
+            return ('committed ' if committed else 'file ') + os.path.relpath(path, ROOT)
+        if os.path.exists(path):
+            log('variant table %s not usable (%s): autotuning' % (path, why))
+    if args.autotune:
+        net.autotune(B)
+        if path and path != 'none' and not committed and rank == 0:
+            T.save_table(net, B, path, note='bench.py autotune')
+        return 'autotuned in this run'
+    return 'heuristic'
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -464,7 +624,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
-    assert world == args.gpus, 'launch with --nproc-per-node == --gpus'
+    if world != args.gpus:
+        print('bench.py: --gpus %d but the launcher started %d rank%s: reporting n_gpus=%d' % (args.gpus, world, '' if world == 1 else 's', world),
+              file=sys.stderr, flush=True)
 
     import romp_amd
     from romp_amd import lib as L, synthetic as S, distributed as D
@@ -485,12 +647,7 @@ def main():
     smpl_model = S.make_smpl_model(0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=smpl_model)
     model.model.set_streams(args.streams)
-    if args.tune_file and os.path.exists(args.tune_file):
-        model.model.set_tuned(B, json.load(open(args.tune_file))[str(B)])
-    elif args.autotune:
-        model.model.autotune(B)
-        if args.tune_file and rank == 0:
-            json.dump({str(B): model.model.tuned_variants(B)}, open(args.tune_file, 'w'))
+    variant_table = install_variants(args, model.model, B, rank, args.backbone, lambda m: print('bench.py: ' + m, file=sys.stderr, flush=True))
     if args.graph:
         model.model.set_graph(True)
     strong = args.global_batch > 0
@@ -517,58 +674,18 @@ def main():
                     break
                 t_lo, t_hi = (mid, t_hi) if kept > 14.0 else (t_lo, mid)
         args.center_thresh = round(mid, 4)
-    persons = 0
-
-    def step():
-        nonlocal persons
-        if world > 1:
-            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts), chunk=B)
-            persons = sum(counts)
-        else:
-            rec = D.local_records(model, images, lo, chunk=B, with_joints=True, with_verts=bool(args.with_verts))
-            persons = 0 if rec is None else rec.shape[0]
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    bb = 'HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'
-    if strong:
-        workload = ('ROMP %s 512x512, batch=%d synthetic images sharded across %d GPU%s (BASELINE configs[2]), each shard walked in forward calls of '
-                    'batch=%d (BASELINE configs[1]); net+parse+SMPL per call%s' %
-                    (bb, G, world, '' if world == 1 else 's', B, ', one RCCL all-gather of the per-person records per step' if world > 1 else ''))
-    else:
-        workload = 'ROMP %s 512x512, batch=%d synthetic images per GPU per step (weak scaling); net+parse+SMPL%s' % (
-            bb, B, '+RCCL all-gather of per-person records' if world > 1 else '')
-    result = {
-        'metric': 'images/sec (512x512, %s)' % bb, 'value': round(G * args.steps / dt, 2), 'unit': 'images/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as %s-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)' % args.conv_math,
-        'data': 'synthetic',
-        'config': {'workload': workload, 'batch_per_call': B, 'global_batch': G, 'images_per_gpu_per_step': n_local,
-                   'ms_per_call': round(dt / args.steps / max(1, -(-n_local // B)) * 1e3, 3),
-                   'persons_per_image': round(persons / G, 2), 'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph),
-                   'autotune': bool(args.autotune), 'branch_streams': bool(args.streams), 'conv_math': args.conv_math,
-                   'parallelism': 'dp%d' % world},
-    }
+        dt, persons = run_job(args, model, images, lo, rank, world, dev, D)
+    result = headline_result(args, dt, persons, G, n_local, world, dev, variant_table)
     if rank == 0:
         first = images[:B]
+        if args.dump_op_kernels:
+            net = model.model
+            json.dump({'batch': B, 'names': net.variant_names(B), 'op_names': list(net.program.names),
+                       'kinds': [int(o.kind) for o in net.program.ops],
+                       'bytes': [float(b) * B for b in net.program.bytes], 'flops': [float(f) * B for f in net.program.flops]},
+                      open(args.dump_op_kernels, 'w'))
         if not args.no_roofline:
             with torch.cuda.stream(stream):
                 roof, classes = roofline_report(model.model, first, pmc_workload=(None if B != 32 else '' if args.backbone == 'hrnet32' else '_' + args.backbone))

@@ -8,12 +8,14 @@ OUT="$REPO/gpurun_out/prof"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export PYTHONUNBUFFERED=1
-# tune once OUTSIDE the profiler and reuse the table, so the traces hold the forward's kernels only
-# (no autotune measuring launches); ${BENCH_ARGS} e.g. "--conv-math f32" or "--workload bev"
-TUNE=/tmp/romp_tune.json
-rm -f $TUNE
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --no-end-to-end --no-latency --global-batch 64 --tune-file $TUNE ${BENCH_ARGS}"
-$BENCH --steps 2 --warmup 1 --no-roofline > "$OUT/bench_plain.log" 2>&1
+# ONE variant table for every pass: the committed one of this configuration (romp_amd/tune/, bench.py's default) when there is
+# one, else a table tuned once OUTSIDE the profiler (${TUNE_FILE}), so the traces hold the forward's kernels only (no autotune
+# measuring launches); ${BENCH_ARGS} e.g. "--conv-math f32" or "--workload bev"
+TUNE_ARG=""
+if [ -n "${TUNE_FILE}" ]; then rm -f "$TUNE_FILE"; TUNE_ARG="--tune-file $TUNE_FILE"; fi
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --no-end-to-end --no-latency --global-batch 64 $TUNE_ARG ${BENCH_ARGS}"
+$BENCH --steps 2 --warmup 1 --no-roofline --dump-op-kernels "$OUT/op_kernels.json" > "$OUT/bench_plain.log" 2>&1
+grep -o '"variant_table": "[^"]*"' "$OUT/bench_plain.log" | head -1
 echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
 echo "stats pass exit $?"
@@ -27,8 +29,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/rp_$C -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$C.log" 2>&1
   echo "pmc $C exit $?"
   f=$(find /tmp/rp_$C -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python "$REPO/scripts/summarize_pmc.py" "$f" $C > "$OUT/pmc_${C}_by_kernel.csv"
+  [ -n "$f" ] && python "$REPO/scripts/summarize_pmc.py" "$f" $C > "$OUT/pmc_${C}_by_kernel.csv" && cp "$f" /tmp/pmc_$C.csv
 done
+# per OP INDEX (what bench.py's roofline.traffic reads): the two passes aligned with the op list of the same variant table
+[ -f /tmp/pmc_FETCH_SIZE.csv ] && [ -f /tmp/pmc_WRITE_SIZE.csv ] && python "$REPO/scripts/pmc_by_op.py" "$OUT/op_kernels.json" /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv "$OUT/pmc_traffic_by_op.json"
 for CS in "MfmaUtil LdsUtil LdsBankConflict" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   TAG=$(echo $CS | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/rp_multi

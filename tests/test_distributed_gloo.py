@@ -142,3 +142,73 @@ def test_sharded_forward_chunked_global_ids():
         for rank, counts, ids, th in res:
             assert ids == want and th == [float(v) for v in want]
             assert sum(counts) == len(want)
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's own job loop (run_job -> timed_steps -> headline_result) on 2 gloo ranks with the stub model."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    from romp_amd import distributed as D
+    sys.argv = ['bench.py', '--gpus', str(world), '--steps', '3', '--warmup', '1', '--batch', '4', '--global-batch', '22']
+    args = bench.parse_args()
+    dev = torch.device('cpu')
+    G = args.global_batch
+    lo, hi = D.shard_range(G, rank, world)
+    images = torch.zeros(hi - lo, 2, 2, 3)
+    images[:, 0, 0, 0] = torch.arange(lo, hi).float()
+    dt, persons = bench.run_job(args, _StubModel(), images, lo, rank, world, dev, D)
+    res = bench.headline_result(args, dt, persons, G, hi - lo, world, dev, 'stub')
+    q.put((rank, res, persons, dt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_job_loop_world2():
+    """the 8-GPU line must not die on launch.  The real control flow of bench.py -- shard, walk in calls of
+    --batch, all-gather once per step, barrier-bracketed timing, MAX over ranks, the result line -- on world size 2 (gloo)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want_persons = sum(v % 3 for v in range(22))
+    dts = {round(r[3], 9) for r in res}
+    assert len(dts) == 1, 'every rank must report the same (max-over-ranks) time'
+    for rank, line, persons, dt in res:
+        assert persons == want_persons
+        assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['steps'] == 3 and line['warmup'] == 1
+        assert line['config']['rccl_ranks'] == 2 and line['config']['backend'] == 'gloo' and line['config']['parallelism'] == 'dp2'
+        assert line['config']['global_batch'] == 22 and line['config']['images_per_gpu_per_step'] == 11
+        assert abs(line['value'] - 22 * 3 / dt) < 0.01 * line['value']
+        assert abs(line['config']['persons_per_image'] - round(want_persons / 22, 2)) < 1e-9
+
+
+def test_bench_respawns_itself_for_multi_gpu(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher environment re-executes under torch.distributed.run instead of asserting."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 0
+    import subprocess
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '2'])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '8'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '8', '--steps', '2']
+    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
