@@ -30,6 +30,7 @@ struct ConvParams {
     int tiles_x, tiles_y, tiles_total;
     int nslices, ns_total;    // channel slices per group; slices*groups
     int n_queues, per_queue;  // 8 (XCD-aware) or 1
+    int tile_contig;          // queue q owns tiles [q * tiles_total / 8, ...) instead of every 8th tile (decode_item)
     int vec_io;               // epilogue may use float4 loads/stores
     int w_gs;                 // floats per group in the packed weight
     int pad_h, pad_w;         // rows / columns of zero padding before the first tap
@@ -139,7 +140,11 @@ constexpr int TRACE_SLOTS = 64, TRACE_WAVES = 4096;
 
 __device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, int NW) {
     const int s = j % p.ns_total, tl = j / p.ns_total;
-    int t = tl * p.n_queues + q;
+    // Which tiles a queue (= an XCD, blockIdx % 8) owns.  tile_contig: a contiguous run of tiles_total / 8 tiles, i.e. whole
+    // images / image halves: the workgroups of one XCD then work on spatially adjacent tiles at the same time and the 3x3
+    // halo re-reads hit that XCD's L2 (round 3: measured FETCH_SIZE of the 16x16-tile 3x3 kernels was 1.27-1.31x algorithmic =
+    // exactly their haloed / plain pixel ratio -- every halo row came over the fabric again).  Else: interleaved (round 1-2).
+    int t = p.tile_contig ? q * (p.tiles_total / p.n_queues) + tl : tl * p.n_queues + q;
     Item it;
     it.g = s / p.nslices;
     it.n0 = (s % p.nslices) * NW;

@@ -224,6 +224,9 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.nslices = op.cout_pad / (v.nt * 32);
     p.ns_total = p.nslices * op.groups;
     p.n_queues = (p.tiles_total % 8 == 0) ? 8 : 1;
+    { static int contig = -1;
+      if (contig < 0) { const char* e = getenv("ROMP_TILE_ORDER"); contig = (e && atoi(e) == 0) ? 0 : 1; }   // ROMP_TILE_ORDER=0: interleaved (A/B runs)
+      p.tile_contig = contig; }
     p.per_queue = (p.tiles_total / p.n_queues) * p.ns_total;
     if (queue == nullptr) {
         queue = g_queue_scratch;

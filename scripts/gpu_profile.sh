@@ -17,6 +17,7 @@ BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --
 $BENCH --steps 2 --warmup 1 --no-roofline --dump-op-kernels "$OUT/op_kernels.json" > "$OUT/bench_plain.log" 2>&1
 grep -o '"variant_table": "[^"]*"' "$OUT/bench_plain.log" | head -1
 echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
+if [ "${PROFILE_ONLY}" != "pmc" ]; then
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
 echo "stats pass exit $?"
 find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
@@ -25,6 +26,7 @@ find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats1 -o stats -- $BENCH --steps 5 --warmup 2 --streams 0 > "$OUT/bench_under_rocprof_serial.log" 2>&1
 echo "serial stats pass exit $?"
 find /tmp/rp_stats1 -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_serial.csv" \;
+fi
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/rp_$C -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$C.log" 2>&1
   echo "pmc $C exit $?"
@@ -32,7 +34,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   [ -n "$f" ] && python "$REPO/scripts/summarize_pmc.py" "$f" $C > "$OUT/pmc_${C}_by_kernel.csv" && cp "$f" /tmp/pmc_$C.csv
 done
 # per OP INDEX (what bench.py's roofline.traffic reads): the two passes aligned with the op list of the same variant table
-[ -f /tmp/pmc_FETCH_SIZE.csv ] && [ -f /tmp/pmc_WRITE_SIZE.csv ] && python "$REPO/scripts/pmc_by_op.py" "$OUT/op_kernels.json" /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv "$OUT/pmc_traffic_by_op.json"
+[ -f /tmp/pmc_FETCH_SIZE.csv ] && [ -f /tmp/pmc_WRITE_SIZE.csv ] && python "$REPO/scripts/pmc_by_op.py" "$OUT/op_kernels.json" /tmp/pmc_FETCH_SIZE.csv /tmp/pmc_WRITE_SIZE.csv "$OUT/pmc_traffic_by_op.json" | tee "$OUT/pmc_traffic_by_op.log"
+[ "${PROFILE_ONLY}" = "pmc" ] && { cat "$OUT/pmc_traffic_by_op.log" 2>/dev/null; exit 0; }
 for CS in "MfmaUtil LdsUtil LdsBankConflict" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   TAG=$(echo $CS | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/rp_multi

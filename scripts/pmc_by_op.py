@@ -48,7 +48,7 @@ def per_op(csv_path, counter, names):
         else:
             merged.append([d, k, v])
     launching = [i for i, n in enumerate(names) if n not in ('fork', 'join')]
-    acc, cnt, forwards, pos = defaultdict(float), defaultdict(int), 0, None
+    acc, cnt, forwards, pos, cur, skipped = defaultdict(float), defaultdict(int), 0, None, {}, []
     for d, k, v in merged:
         m = NET_KERNEL.search(k)
         if not m:
@@ -57,18 +57,25 @@ def per_op(csv_path, counter, names):
             pos = 0
         if pos is None:
             continue
-        if pos >= len(launching):
-            raise SystemExit('more network kernels after a stem than ops (%d): %s' % (len(launching), k))
+        if pos == 0:
+            cur = {}
         i = launching[pos]
         want = kernel_of(names[i])
         if want is not None and want not in k:
-            raise SystemExit('dispatch %d is %s, op %d of the table is %s: the pass ran another variant table' % (d, k[:80], i, names[i]))
-        acc[i] += v * 1024.0
-        cnt[i] += 1
+            # not a forward of the profiled table (the float32 calibration forward at start-up, an autotune launch): drop it
+            skipped.append('dispatch %d is %s, op %d of the table is %s' % (d, k[:60], i, names[i]))
+            pos = None
+            continue
+        cur[i] = v * 1024.0
         pos += 1
         if pos == len(launching):
+            for j, b in cur.items():
+                acc[j] += b
+                cnt[j] += 1
             forwards += 1
             pos = None
+    if forwards == 0:
+        raise SystemExit('no forward of the table found in %s; first mismatches: %s' % (csv_path, skipped[:3]))
     return {i: acc[i] / cnt[i] for i in acc}, forwards
 
 
