@@ -79,21 +79,6 @@ def parse_args():
 
 
 # ------------------------------------------------------------------------------------------------ roofline
-def kernel_of(variant_name):
-    import re
-    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
-    if not m:
-        return None
-    fam, ks, s, mt, nt, tw, ck = m.groups()
-    if fam in ('h2q', 'h2r'):
-        return 'conv_%s_kernel<%s, %s, %s>' % (fam, mt, nt, tw)
-    if fam in ('h2p', 'h2w'):
-        return 'conv_h2p_kernel<%s, %s, %s, %s>' % (mt, nt, tw, 'true' if fam == 'h2w' else 'false')
-    if fam in ('h2o', 'h2do'):
-        fam += '4'
-    return 'conv_%s_kernel<%s, %s, %s, %s, %s, %s>' % (fam, ks, s, mt, nt, tw, ck)
-
-
 def pmc_traffic(op_ids, op_names, pmc_dir, workload=''):
     """Measured HBM bytes per launch over the op index set `op_ids`, from the committed rocprofv3 --pmc passes of this same
     command (profiles/<tag><workload>_pmc_traffic_by_op.json, written by scripts/summarize_pmc.py --by-op from separate

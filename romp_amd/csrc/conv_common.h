@@ -320,8 +320,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
 
 typedef void (*conv_fn)(ConvParams);
 // math: 0 f32 MFMA, 1 bf16x3 (register-staged weights), 2 bf16x3 (LDS-DMA weight rows), 3 / 4 the same two for f16x2,
-// 5 f16x2 fully LDS-DMA-fed pipeline (conv_h2p.hip), 6 the same with the layer's weights resident in LDS,
-// 7 its producer / consumer form (4 MFMA waves + 4 DMA waves), 8 f16x2 with register-resident weights (conv_h2r.hip).  threads: workgroup size (0 = 256, or 512 for the ping-pong kernels).
+// 8 f16x2 with register-resident weights (conv_h2r.hip).  (5 / 6 / 7 were round 2's LDS-DMA pipeline kernels, now
+// scripts/attic/conv_h2p.hip: never faster than 3 / 4 / 8 inside the network.)  threads: workgroup size (0 = 256, or 512 for the ping-pong kernels).
 // o4: the same kernel compiled for four workgroups per CU (128 VGPRs; named conv_h2o).
 struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; int threads; int o4; };
 
@@ -330,7 +330,6 @@ ConvVariant* conv_variants_f32(int* n);
 ConvVariant* conv_variants_bx3(int* n);
 ConvVariant* conv_variants_h2(int* n);
 ConvVariant* conv_variants_h2d(int* n);
-ConvVariant* conv_variants_h2p(int* n);
 ConvVariant* conv_variants_h2r(int* n);
 
 }  // namespace romp

@@ -13,7 +13,7 @@
 //     LDS bytes per MFMA.  The registers of tap t are re-loaded for the NEXT stage as soon as tap t's last MFMA has been
 //     issued, so the prefetch costs no registers of its own and has a whole stage to land;
 //   * LDS holds nothing but two pixel stage buffers (haloed tile x 16 channels, pre-split H2 units copied by LDS-DMA in the
-//     rotated layout of conv_h2p.hip) and the per-wave epilogue staging tiles: 46-67 KB, two workgroups per CU with room for
+//     rotated layout described at the descriptors below) and the per-wave epilogue staging tiles: 46-67 KB, two workgroups per CU with room for
 //     a kernel of another HRNet branch stream;
 //   * a stage is 9 x P / 2 units of [4 fragment reads, 6 MFMAs on alternating accumulators] per wave, the reads software-
 //     pipelined two units ahead through a register ring, the DMA pieces of the next stage and the weight reloads issued at the

@@ -46,7 +46,6 @@ static void collect_variants() {
     t = conv_variants_bx3(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2d(&n); kVariants.insert(kVariants.end(), t, t + n);
-    t = conv_variants_h2p(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2r(&n); kVariants.insert(kVariants.end(), t, t + n);
     kNumVariants = (int)kVariants.size();
 }
@@ -93,24 +92,12 @@ static int ensure_attrs() {
 // that it never runs inside a stream capture (hipMalloc / hipFuncSetAttribute are illegal there).
 int conv_init() { return ensure_attrs(); }
 
-// The LDS-DMA pipeline kernels (conv_h2p.hip) take a whole CU per workgroup.  Measured alone they beat the two-per-CU f16x2
-// kernels by 5-10 % on the 64- and 128-channel layers, but inside the network the kernels of the other branch streams can no
-// longer share their CUs and the batch-32 forward got 11 % SLOWER (2 066 vs 2 327 images/s), so the autotuner only sees them
-// when ROMP_CONV_PIPE=1.  Explicit variant indices (tests, scripts/conv_ablate.py) always work.
-static int g_pipe_auto = -1;
-static bool pipe_in_autotune() {
-    if (g_pipe_auto < 0) { const char* e = getenv("ROMP_CONV_PIPE"); g_pipe_auto = (e && atoi(e)) ? 1 : 0; }
-    return g_pipe_auto == 1;
-}
-
 static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) {
     if (v.lds > kMaxLds) return false;
     if ((v.math == 1 || v.math == 2) && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.math >= 3 && (op.weight_h2 == nullptr || op.scale_h2 == nullptr || (op.cin_pad & 15))) return false;
     if (op.in_fmt == ROMP_FMT_H2 && v.math < 3) return false;
-    if (v.math >= 5 && v.math != 8 && (op.in_fmt != ROMP_FMT_H2 || op.cin_pad < 32)) return false;
     if (v.math == 8 && op.in_fmt != ROMP_FMT_H2) return false;                         // register-weight kernels: pixels arrive by LDS-DMA too   // the DMA pipeline copies pre-split pixels
-    if (v.math == 6 && (op.cin_pad != 32 || op.cout_pad != v.nt * 32 || op.groups != 1)) return false;   // resident weights: one slab for every item          // only the f16x2 kernels stage pre-split activations
     if ((op.out_fmt == ROMP_FMT_H2 || op.res_fmt == ROMP_FMT_H2) && !(op.Cout == op.cout_pad)) return false;   // vector epilogue only
     if (v.ks != op.ksize || v.s != op.stride) return false;
     if (Wo % v.tw) return false;                     // rows may be partial (masked), columns may not
@@ -150,7 +137,7 @@ static int g_no_h2r = -1;                   // env ROMP_CONV_NO_H2R=1: keep the 
 bool conv_variant_tunable(const romp_op& op, int variant) {
     if (g_no_h2r < 0) { const char* e = getenv("ROMP_CONV_NO_H2R"); g_no_h2r = (e && atoi(e)) ? 1 : 0; }
     if (kVariants[variant].math == 8 && g_no_h2r) return false;
-    return conv_variant_valid(op, variant) && (kVariants[variant].math < 5 || kVariants[variant].math == 8 || pipe_in_autotune());
+    return conv_variant_valid(op, variant);
 }
 
 bool conv_variant_valid(const romp_op& op, int variant) {
@@ -262,7 +249,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 8 ? "conv_h2r" : v.math == 7 ? "conv_h2q" : v.math == 6 ? "conv_h2w" : v.math == 5 ? "conv_h2p" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 8 ? "conv_h2r" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }

@@ -45,7 +45,8 @@ struct romp_net {
     int max_batch = 0;
     int mode = 0;
     int use_graph = 0;
-    int first_op = 0;                    // run_lane starts here (graph replay: the stem, the only reader of the caller's image, runs eagerly)
+    bool image_only_in_op0 = false;      // ops[0] is a stem and no later op reads ROMP_BUF_IMAGE (checked at create): graph replay may then
+                                         // launch the stem eagerly and key the graph without the image pointer
     int use_streams = 1;                 // run FORK/JOIN regions on side streams
     // Batch lanes: with split == 2 a forward of B images runs as two independent half-batch op sequences
     // on two streams (lane 0 on the caller's stream), each conv capped at one workgroup per CU, so the
@@ -199,11 +200,11 @@ static int reset_queues(romp_net* n, hipStream_t st) {
 
 // One op sequence (a whole batch, or one batch lane) on `st` with its FORK/JOIN regions on the lane's side streams.
 static int run_lane(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st, int lane, int b0,
-                    hipEvent_t ev_after_first_convs) {
+                    hipEvent_t ev_after_first_convs, size_t first_op = 0) {
     const std::vector<int>* tv = tuned_for(n, B);
     const bool ms = n->use_streams && n->mode == 0;
     int convs_seen = 0;
-    for (size_t i = (size_t)n->first_op; i < n->ops.size(); ++i) {
+    for (size_t i = first_op; i < n->ops.size(); ++i) {
         const romp_op& op = n->ops[i];
         if (op.kind == ROMP_OP_FORK) {
             if (!ms) continue;
@@ -231,13 +232,13 @@ static int run_lane(romp_net* n, const float* image, int B, float* center, float
 
 static bool lanes_active(const romp_net* n, int B) { return n->split == 2 && n->mode == 0 && B >= 2 && !(B & 1); }
 
-static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st) {
+static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st, size_t first_op = 0) {
     int rc = reset_queues(n, st);
     if (rc) return rc;
     if (!lanes_active(n, B)) {
         const int cap = n->wg_cap;
         if (n->split == 2) n->wg_cap = 0;              // an unsplit forward (odd / single-image batch) takes the whole chip
-        rc = run_lane(n, image, B, center, params, st, 0, 0, nullptr);
+        rc = run_lane(n, image, B, center, params, st, 0, 0, nullptr, first_op);
         n->wg_cap = cap;
         return rc;
     }
@@ -269,6 +270,14 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
     n->ops.assign(ops_host, ops_host + n_ops);
     n->buf_floats.assign(buf_floats, buf_floats + n_bufs);
     n->max_batch = max_batch;
+    // graph replay launches op 0 eagerly and bakes no image pointer into the graph: only sound if nothing else reads the image
+    n->image_only_in_op0 = n_ops > 0 && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
+    for (int i = 1; i < n_ops && n->image_only_in_op0; ++i) {
+        const romp_op& o = n->ops[i];
+        bool reads = o.in_buf == ROMP_BUF_IMAGE || o.res_buf == ROMP_BUF_IMAGE;
+        for (int k = 0; k < 4; ++k) reads |= (o.kind == ROMP_OP_FUSESUM && k < o.n_terms && o.term_buf[k] == ROMP_BUF_IMAGE);
+        if (reads) n->image_only_in_op0 = false;
+    }
     n->bufs.resize(n_bufs, nullptr);
     for (int i = 0; i < n_bufs; ++i) {
         const size_t bytes = (size_t)buf_floats[i] * max_batch * sizeof(float);
@@ -344,7 +353,7 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     // The stem is the only op that reads the caller's image: launched eagerly in front of the graph, the graph no longer
     // depends on WHERE the input lives (a caller streaming frames from ever new tensors replays one graph).
     static const bool stem_in_graph = getenv("ROMP_STEM_IN_GRAPH") != nullptr;      // A/B switch for the measurement in DESIGN.md
-    const bool stem_out = !stem_in_graph && !lanes_active(n, B) && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
+    const bool stem_out = !stem_in_graph && !lanes_active(n, B) && n->image_only_in_op0;
     const float* key_image = stem_out ? nullptr : image;
     if (n->graphs.size() >= 32 && !n->graphs.count(GraphKey{B, key_image, center, params, lanes_active(n, B) ? 0 : -1})) {
         // a caller that hands over new tensors every call must not grow the cache for ever
@@ -372,9 +381,7 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
             const int rc0 = run_op(n, 0, -1, image, B, center, params, st);
             if (rc0) return rc0;
         }
-        n->first_op = stem_out ? 1 : 0;
-        const int rc = capture(st, key, [&] { return run_all(n, image, B, center, params, st); });
-        n->first_op = 0;
+        const int rc = capture(st, key, [&] { return run_all(n, image, B, center, params, st, stem_out ? 1 : 0); });
         if (rc) return rc;
         ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[key], st));
         return ROMP_OK;
@@ -688,9 +695,18 @@ int romp_net_load(romp_net** out, const char* path, int max_batch) {
     ROMP_REQUIRE(h.abi == ROMP_ABI_VERSION && h.op_bytes == sizeof(romp_op), "romp_net_load: plan was written for ABI %u (romp_op %u bytes), this library is ABI %d (%zu bytes)",
                  h.abi, h.op_bytes, ROMP_ABI_VERSION, sizeof(romp_op));
     size_t at = sizeof(PlanHeader);
-    const size_t need = at + (size_t)h.n_bufs * 8 + (size_t)h.n_ops * sizeof(romp_op) + (size_t)h.n_inits * sizeof(PlanInit) +
-                        (size_t)h.n_tuned * (2 + h.n_ops) * 4 + h.dev_bytes + h.host_bytes;
-    ROMP_REQUIRE(h.n_ops > 0 && need == file.size(), "romp_net_load: %s: size %zu does not match its header (%zu)", path, file.size(), need);
+    // every header field is bounded by the file size BEFORE it enters a product or a sum (a corrupted or crafted header must
+    // not wrap the size check), then the sections must add up to the file exactly
+    const uint64_t fsz = file.size();
+    ROMP_REQUIRE(h.n_ops > 0 && h.n_ops <= fsz / sizeof(romp_op) && h.n_bufs <= fsz / 8 && h.n_inits <= fsz / sizeof(PlanInit) &&
+                 h.dev_bytes <= fsz && h.host_bytes <= fsz && (h.n_tuned == 0 || h.n_tuned <= fsz / (4ull * (2 + (uint64_t)h.n_ops))),
+                 "romp_net_load: %s: header fields exceed the file size", path);
+    uint64_t need = at;
+    const uint64_t parts[] = {(uint64_t)h.n_bufs * 8, (uint64_t)h.n_ops * sizeof(romp_op), (uint64_t)h.n_inits * sizeof(PlanInit),
+                              (uint64_t)h.n_tuned * (2 + (uint64_t)h.n_ops) * 4, h.dev_bytes, h.host_bytes};
+    bool overflow = false;
+    for (uint64_t part : parts) overflow |= __builtin_add_overflow(need, part, &need);
+    ROMP_REQUIRE(!overflow && need == fsz, "romp_net_load: %s: size %zu does not match its header", path, file.size());
     std::vector<int64_t> buf_floats(h.n_bufs);
     memcpy(buf_floats.data(), file.data() + at, (size_t)h.n_bufs * 8); at += (size_t)h.n_bufs * 8;
     std::vector<romp_op> ops(h.n_ops);
@@ -730,7 +746,8 @@ int romp_net_load(romp_net** out, const char* path, int max_batch) {
     n->plan_center_floats = (int64_t)h.center_floats;
     n->plan_params_floats = (int64_t)h.params_floats;
     for (const PlanInit& in : inits) {
-        if (in.buf < 0 || in.buf >= (int)h.n_bufs || (int64_t)in.floats > buf_floats[in.buf] || in.dev_off + in.floats * 4 > h.dev_bytes) {
+        if (in.buf < 0 || in.buf >= (int)h.n_bufs || buf_floats[in.buf] < 0 || in.floats > (uint64_t)buf_floats[in.buf] ||
+            in.dev_off > h.dev_bytes || in.floats > (h.dev_bytes - in.dev_off) / 4) {      // (no sum that could wrap)
             set_error("romp_net_load: %s: bad buffer initialiser", path);
             romp_net_destroy(n);
             return ROMP_EINVAL;

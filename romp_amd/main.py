@@ -20,7 +20,7 @@ from torch import nn
 
 from . import lib as L
 from .net import RompNet
-from .post_parser import (_HAVE_CV2, CenterMap, SMPL_parser, body_mesh_projection2image, convert_cam_to_3d_trans,
+from .post_parser import (_HAVE_CV2, CenterMap, SMPL_parser, body_mesh_projection2image, convert_cam_to_3d_trans, pnp_translation,
                           parsing_outputs)
 from .vis import rendering_romp_bev_results, setup_renderer
 from .utils import ResultSaver, convert_tensor2numpy, determine_device, img_preprocess, img_preprocess_device
@@ -204,8 +204,9 @@ class ROMP(nn.Module):
                                    L.ptr(views['smpl_thetas']), L.ptr(views['smpl_betas']), L.ptr(ibuf[2 * cap:]), L.ptr(ibuf[4 * cap:]),
                                    L.stream_ptr(dev)))
         verts, joints, _ = self.smpl_parser.smpl_model(views['smpl_betas'], views['smpl_thetas'], root_align=self.settings.root_align)
-        proj = body_mesh_projection2image(joints, views['cam'], input2org_offsets=pad)
-        small = torch.cat([ibuf.view(torch.float32), fbuf, proj['cam_trans'].reshape(-1), joints.reshape(-1), proj['pj2d_org'].reshape(-1)])
+        proj = body_mesh_projection2image(joints, views['cam'], input2org_offsets=pad, host_pnp=False)
+        small = torch.cat([ibuf.view(torch.float32), fbuf, proj['cam_trans'].reshape(-1), joints.reshape(-1), proj['pj2d_org'].reshape(-1),
+                           proj['pj2d'].reshape(-1)])
         host = small.cpu().numpy()                                   # the one synchronisation point of the frame
         hi = host[:ibuf.numel()].view(np.int32)
         N = int(hi[4 * cap + 2 * cap])
@@ -215,9 +216,13 @@ class ROMP(nn.Module):
         hf = host[ibuf.numel():]
         out, at = {}, 0
         for key, w in (('scores', 1), ('params_pred', 145), ('cam', 3), ('smpl_thetas', 72), ('smpl_betas', 10), ('cam_trans', 3),
-                       ('joints', 213), ('pj2d_org', 142)):
+                       ('joints', 213), ('pj2d_org', 142), ('pj2d', 142)):
             out[key] = hf[at:at + cap * w].reshape(cap, w)[:N]
             at += cap * w
+        if _HAVE_CV2:                                                # OpenCV installed: the reference's PnP translation, on the rows just downloaded
+            t = pnp_translation(out['joints'].reshape(N, 71, 3)[:, :24], (out['pj2d'].reshape(N, 71, 2)[:, :24] + 1) * 256)
+            if t is not None:
+                out['cam_trans'] = t
         th = out['smpl_thetas']
         return {'cam': out['cam'], 'global_orient': np.ascontiguousarray(th[:, :3]), 'body_pose': np.ascontiguousarray(th[:, 3:]),
                 'smpl_betas': out['smpl_betas'], 'smpl_thetas': th, 'center_preds': hi[2 * cap:4 * cap].reshape(cap, 2)[:N].astype(np.int64),
@@ -228,7 +233,7 @@ class ROMP(nn.Module):
         """main.py:160-176: BGR uint8 HxWx3 numpy -> dict of numpy arrays, or None."""
         s = self.settings
         if (getattr(self, 'fast_single', True) and s.calc_smpl and not s.temporal_optimize and not s.render_mesh
-                and not getattr(s, 'host_preprocess', False) and not _HAVE_CV2):
+                and not getattr(s, 'host_preprocess', False)):
             return self._forward_fast(image)
         outputs, image_pad_info = self.single_image_forward(image)
         if outputs is None:

@@ -145,10 +145,30 @@ def estimate_translation_lsq(joints_3d, joints_2d, focal_length=443.4, img_size=
     return out
 
 
-def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_offsets=None):
+def pnp_translation(j24, p24):
+    """The reference's first-choice camera translation (post_parser.py:96-101 -> utils.py:391-434): cv2.solvePnPRansac per person on
+    the host.  j24 (N,24,3), p24 (N,24,2) numpy in the 512-pixel input frame -> (N,3) float32, or None without OpenCV / on failure."""
+    if not _HAVE_CV2:
+        return None
+    import cv2
+    camK = np.eye(3)
+    camK[0, 0] = camK[1, 1] = 443.4
+    camK[:2, 2] = 256
+    try:
+        t = np.zeros((len(j24), 3), np.float32)
+        for i in range(len(j24)):
+            ret, rvec, tvec, inl = cv2.solvePnPRansac(j24[i], p24[i], camK, None, flags=cv2.SOLVEPNP_EPNP,
+                                                      reprojectionError=20, iterationsCount=100)
+            t[i] = -1 if inl is None else tvec[:, 0]
+        return t
+    except Exception:
+        return None
+
+
+def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_offsets=None, host_pnp=True):
     """post_parser.py:104-114.  pj2d / pj2d_org on device (csrc/parse.hip project_kernel);
     `cam_trans` follows the reference's PnP step (post_parser.py:96-101): cv2.solvePnPRansac on the host when OpenCV is
-    installed, else the reference's own least-squares fallback (utils.py:347-389) on the device
+    installed (`pnp_translation`), else the reference's own least-squares fallback (utils.py:347-389) on the device
     (csrc/parse.hip translation_lsq_kernel; `estimate_translation_lsq` below is its host statement)."""
     lib = L.load()
     dev = j3d_preds.device
@@ -164,22 +184,10 @@ def body_mesh_projection2image(j3d_preds, cam_preds, vertices=None, input2org_of
         L.check(lib.romp_project(L.ptr(j), N, J, L.ptr(cam), pad_c, L.ptr(pj2d), L.ptr(pj2d_org), L.ptr(ct),
                                  L.stream_ptr(dev)))
     trans = None
-    if _HAVE_CV2:                                                      # the reference's first choice: OpenCV PnP on the host
-        import cv2
-        j24 = j[:, :24].detach().cpu().numpy()
-        p24 = (pj2d[:, :24].detach().cpu().numpy() + 1) * 256        # post_parser.py:98
-        camK = np.eye(3)
-        camK[0, 0] = camK[1, 1] = 443.4
-        camK[:2, 2] = 256
-        try:
-            t = np.zeros((N, 3), np.float32)
-            for i in range(N):
-                ret, rvec, tvec, inl = cv2.solvePnPRansac(j24[i], p24[i], camK, None, flags=cv2.SOLVEPNP_EPNP,
-                                                          reprojectionError=20, iterationsCount=100)
-                t[i] = -1 if inl is None else tvec[:, 0]
-            trans = torch.from_numpy(t).float().to(dev)
-        except Exception:
-            trans = None
+    if _HAVE_CV2 and host_pnp:                                         # the reference's first choice: OpenCV PnP on the host
+        # (host_pnp=False: the caller runs pnp_translation itself on arrays it downloads anyway -- ROMP._forward_fast)
+        t = pnp_translation(j[:, :24].detach().cpu().numpy(), (pj2d[:, :24].detach().cpu().numpy() + 1) * 256)   # post_parser.py:98
+        trans = None if t is None else torch.from_numpy(t).float().to(dev)
     if trans is None:                                                  # its fallback, the linear least squares: on the device
         trans = torch.empty(N, 3, device=dev)
         with torch.cuda.device(dev):

@@ -21,9 +21,7 @@ class OneEuroBank(object):
     def _slots_for(self, track_ids):
         """Rows of self.state for the tracks of ONE call.  The table is cleared (utils.py:253-254 drops all filters of a source
         that has grown too large) BEFORE any row of this call is handed out, so two tracks of a call never share a row."""
-        if len(set(track_ids)) != len(track_ids):
-            raise L.RompHipError('OneEuroBank.smooth: duplicate track ids %s' % list(track_ids))
-        if len(track_ids) > self.state.shape[0]:
+        if len(set(track_ids)) > self.state.shape[0]:
             raise L.RompHipError('OneEuroBank.smooth: %d tracks, capacity %d' % (len(track_ids), self.state.shape[0]))
         fresh = [t for t in track_ids if t not in self.slots]
         if len(self.slots) + len(fresh) > self.state.shape[0]:
@@ -38,10 +36,32 @@ class OneEuroBank(object):
         return [self.slots[t] for t in track_ids]
 
     def smooth(self, track_ids, thetas, betas, cam):
-        """In place on thetas (N,72), betas (N,nb), cam (N,3) (device float32, contiguous); returns them."""
+        """In place on thetas (N,72), betas (N,nb), cam (N,3) (device float32, contiguous); returns them.
+        Two detections of a frame may carry the SAME track id (ROMP's get_tracked_ids gives each detection the id of its nearest
+        tracked object, utils.py:493-533); the reference then runs that track's filters twice, in detection order
+        (main.py:141-157).  The kernel updates every row of a call from the same previous state, so the rounds below do the same:
+        first occurrences in one batched launch, second occurrences in the next (on the state the first just wrote), ..."""
         assert thetas.is_contiguous() and betas.is_contiguous() and cam.is_contiguous() and thetas.dtype == torch.float32
-        slots = torch.tensor(self._slots_for(track_ids), dtype=torch.int32, device=self.device)
+        track_ids = list(track_ids)
+        unique = list(dict.fromkeys(track_ids))
+        rows_of = dict(zip(unique, self._slots_for(unique)))
+        seen, rounds = {}, []
+        for i, t in enumerate(track_ids):
+            k = seen.get(t, 0)
+            seen[t] = k + 1
+            while len(rounds) <= k:
+                rounds.append([])
+            rounds[k].append(i)
         with torch.cuda.device(self.device):
-            L.check(self.lib.romp_oneeuro_smooth(L.ptr(self.state), L.ptr(slots), len(track_ids), self.n_betas, self.smooth_coeff,
-                                                 L.ptr(thetas), L.ptr(betas), L.ptr(cam), L.stream_ptr(self.device)))
+            for idx in rounds:
+                slots = torch.tensor([rows_of[track_ids[i]] for i in idx], dtype=torch.int32, device=self.device)
+                if len(idx) == len(track_ids):                    # the common case: no duplicates, filter in place
+                    th, be, ca = thetas, betas, cam
+                else:
+                    sel = torch.tensor(idx, dtype=torch.int64, device=self.device)
+                    th, be, ca = thetas[sel].contiguous(), betas[sel].contiguous(), cam[sel].contiguous()
+                L.check(self.lib.romp_oneeuro_smooth(L.ptr(self.state), L.ptr(slots), len(idx), self.n_betas, self.smooth_coeff,
+                                                     L.ptr(th), L.ptr(be), L.ptr(ca), L.stream_ptr(self.device)))
+                if th is not thetas:
+                    thetas[sel], betas[sel], cam[sel] = th, be, ca
         return thetas, betas, cam

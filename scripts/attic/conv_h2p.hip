@@ -1,3 +1,5 @@
+// ATTIC (round 3): measured negative result, no longer part of libromp_hip.so (VERDICT r2 #8e).  To revive: copy next to
+// romp_amd/csrc/conv_split.h, add to build.py SOURCES and to collect_variants() in conv_mfma.hip (math codes 5 / 6 / 7).
 // conv_h2p.hip -- 3x3 stride-1 convolution on the f16x2 split (conv_split.h), third generation: a software pipeline fed
 // ENTIRELY by LDS-DMA.
 //

@@ -126,3 +126,47 @@ def test_resnet_net_vs_oracle(dev, bf16x3):
         assert ec < 1e-4 and ep < 1e-4
     if bf16x3:
         assert sum('bx' in n for n in net.variant_names(2)) > 0
+
+
+@pytest.mark.parametrize('size', [(1920, 1080), (1280, 720)], ids=['1080p', '720p'])
+def test_configs0_demo_shaped_jpeg_through_the_api(dev, size, tmp_path):
+    """BASELINE configs[0] as written: `ROMP(--backbone resnet50)(image)` on a demo-image-shaped input.  /root/reference/demo/images
+    does not exist on the GPU box, so the frame is a synthetic JPEG of the demo images' sizes (1920x1080, 1280x720) written and
+    decoded with PIL, fed as the BGR uint8 array cv2.imread would return.  The drop-in's result dict (reference keys, dtypes,
+    shapes) must equal the oracle pipeline -- ResNet-50 network, parse, SMPL -- on the oracle's own pre-processing of the same
+    frame (pad to square + INTER_CUBIC resize, oracle/cv_resize_oracle.py)."""
+    from PIL import Image
+    import romp_amd
+    from oracle import cv_resize_oracle as CV
+    W, H = size
+    rs = np.random.RandomState(W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    rgb = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx + yy) % 256)], -1).astype(np.uint8)
+    rgb[H // 4: H // 4 * 3, W // 3: W // 3 * 2] = rs.randint(0, 256, (H // 4 * 3 - H // 4, W // 3 * 2 - W // 3, 3), dtype=np.uint8)
+    path = str(tmp_path / 'demo.jpg')
+    Image.fromarray(rgb).save(path, quality=92)
+    bgr = np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1])      # what cv2.imread(path) yields
+    assert bgr.shape == (H, W, 3) and bgr.dtype == np.uint8
+    sd = RO.make_resnet_state_dict(0, center_bias=2.0)
+    smpl = O.make_synthetic_smpl(0)
+    s = romp_amd.romp_settings(['--backbone', 'resnet50'])
+    s.GPU, s.max_batch = 0, 1
+    model = romp_amd.ROMP(s, state_dict=sd, smpl_model=smpl)
+    # a threshold that keeps a handful of persons with these random weights (outside what is compared)
+    x = torch.from_numpy(CV.img_preprocess(bgr)[0]).float()
+    cm_o, pm_o = RO.resnet_romp_forward(sd, x)
+    peaks = np.sort(cm_o.numpy().reshape(-1))[::-1]
+    model.centermap_parser.conf_thresh = thresh = float(0.5 * (peaks[40] + peaks[41]))
+    out = model(bgr)
+    ref = O.parsing_outputs(cm_o.numpy(), pm_o.numpy(), thresh)
+    assert out is not None and ref is not None
+    for k in ('cam', 'global_orient', 'body_pose', 'smpl_betas', 'smpl_thetas', 'center_preds', 'center_confs', 'cam_trans', 'verts', 'joints', 'pj2d_org'):
+        assert k in out and isinstance(out[k], np.ndarray), k
+    N = len(ref['batch_ids'])
+    assert out['verts'].shape == (N, 6890, 3) and out['joints'].shape == (N, 71, 3) and out['pj2d_org'].shape == (N, 71, 2)
+    assert np.array_equal(out['center_preds'], ref['center_preds'])
+    assert np.abs(out['smpl_thetas'] - ref['smpl_thetas']).max() < 1e-3
+    vo, jo, _ = O.smpl_forward(smpl, out['smpl_betas'], out['smpl_thetas'])
+    ev = float(np.abs(out['verts'] - vo).max())
+    print('%dx%d JPEG through ROMP(resnet50): %d persons, verts vs oracle on identical theta/beta %.2e' % (W, H, N, ev))
+    assert ev < 1e-4

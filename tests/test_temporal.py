@@ -76,6 +76,26 @@ def test_hip_filter_multi_track(dev):
 
 
 @pytest.mark.gpu
+def test_hip_filter_duplicate_track_ids(dev):
+    """Two detections of one frame with the SAME track id (ROMP's nearest-track association can do that): the reference runs the
+    track's filters twice, in detection order (main.py:141-157) -- so must the bank, instead of refusing the frame."""
+    from romp_amd.temporal import OneEuroBank
+    seq_a, seq_b = TO.make_sequence(seed=31, frames=4), TO.make_sequence(seed=32, frames=4)
+    bank = OneEuroBank(dev, 3.0, 10)
+    f7, f8 = TO.make_filters(3.0), TO.make_filters(3.0)
+    for f in range(4):
+        rows = [(7, seq_a[f]), (8, seq_b[f]), (7, seq_b[f])] if f % 2 else [(7, seq_a[f]), (8, seq_b[f])]
+        th = torch.stack([r[1][0] for r in rows]).to(dev).contiguous()
+        be = torch.stack([r[1][1] for r in rows]).to(dev).contiguous()
+        ca = torch.stack([r[1][2] for r in rows]).to(dev).contiguous()
+        bank.smooth([r[0] for r in rows], th, be, ca)
+        for i, (tid, x) in enumerate(rows):                       # the oracle, applied sequentially in detection order
+            to, bo, co = TO.smooth(f7 if tid == 7 else f8, *x)
+            assert (th[i].cpu() - to).abs().max() < 2e-5 and (be[i].cpu() - bo).abs().max() < 2e-5 and (ca[i].cpu() - co).abs().max() < 2e-5
+    assert len(bank.slots) == 2
+
+
+@pytest.mark.gpu
 def test_romp_temporal_show_largest(dev):
     """ROMP(settings: -t --show_largest): the largest person's thetas/betas/cam are filtered across frames
     (main.py:119-126); the meshes are computed from the smoothed parameters."""
