@@ -83,11 +83,19 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
         v.x = fmaxf(fmaf(acc[t].x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(acc[t].y, sc.y, sh.y), 0.f);
         v.z = fmaxf(fmaf(acc[t].z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(acc[t].w, sc.w, sh.w), 0.f);
         if (p.out_h2) {                                   // channels 4cg..4cg+3 = half (cg & 1) of octet cg >> 1
+            // The two lanes of an octet trade halves so that each stores ONE whole 16-byte unit (even lane: the eight high
+            // pieces, odd lane: the eight low pieces): a wave's store covers 4 pixels x 256 contiguous bytes, instead of two
+            // instructions of 8-byte pieces on alternating 16-byte slots (the 8-byte stores had this kernel at 2.2 TB/s)
             uint2 hi, lo;
             h2_pack(v, p.act_scale, hi, lo);
-            char* o = reinterpret_cast<char*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + (cg >> 1) * 8) + (cg & 1) * 8;
-            *reinterpret_cast<uint2*>(o) = hi;
-            *reinterpret_cast<uint2*>(o + 16) = lo;
+            const bool odd = cg & 1;
+            const uint2 send = odd ? hi : lo;
+            uint2 recv;
+            recv.x = __shfl_xor(send.x, 1);
+            recv.y = __shfl_xor(send.y, 1);
+            const uint4 unit = odd ? make_uint4(recv.x, recv.y, lo.x, lo.y) : make_uint4(hi.x, hi.y, recv.x, recv.y);
+            char* o = reinterpret_cast<char*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + (cg >> 1) * 8) + (odd ? 16 : 0);
+            *reinterpret_cast<uint4*>(o) = unit;
         } else {
             *reinterpret_cast<float4*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + cg * 4) = v;
         }

@@ -23,7 +23,8 @@ from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, 
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
-HEAD_IN_CH = 40          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 8
+HEAD_IN_CH = 48          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 16 (the f16x2 kernels' channel chunk:
+                         # with 40 the head's first conv was the one layer left on the f32 kernels)
 
 
 @dataclass
@@ -648,6 +649,7 @@ def build_romp_head(P: Program, sd, head_x: Act, cin: int):
         s, b = fold_bn(sd, p + '1', 64, sd[p + '0.bias'])
         w0.append(wp); s0.append(s); b0.append(b)
     t = P.conv('head.conv0', head_x, [torch.cat(w0, 0)], [torch.cat(s0)], [torch.cat(b0)], 3, 2, True)
+    P.flops[-1] *= cin / float(head_x.C)                         # algorithmic work: the reference's `cin` channels, not the zero padding
     for blk in range(2):
         ws1, ss1, bs1, ws2, ss2, bs2 = [], [], [], [], [], []
         for h in heads:

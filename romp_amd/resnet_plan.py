@@ -18,7 +18,7 @@ from .plan import Act, Program, build_romp_head, fold_bn, _clean, set_conv_math,
 
 OP_STEM7, OP_MAXPOOL = 9, 10
 LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
-RESNET_HEAD_CH = 72       # 64 backbone + 2 CoordConv channels, zero-padded to a multiple of 8
+RESNET_HEAD_CH = 80       # 64 backbone + 2 CoordConv channels, zero-padded to a multiple of 16 (f16x2 channel chunk)
 
 
 def _stem7(P: Program, name, w, scale, shift, H, W):
