@@ -76,6 +76,11 @@ const char* romp_last_error(void);
 #define ROMP_OP_KSUM      11    /* tail of a split-K conv (single-image latency plans): in_buf holds `groups` float32 partial sums of
                                    Cout channels each per pixel (a grouped ROMP_OP_CONV over input-channel slices wrote them);
                                    y = scale * sum_g partial_g + shift (+res) (+ReLU), H x W = the OUTPUT size                  */
+#define ROMP_OP_NOP       12    /* executes nothing (its fields may describe a layer that the next op runs fused)                 */
+#define ROMP_OP_BBLOCK32  13    /* a whole 32-channel BasicBlock (model.py:54-83) in one kernel: this op holds the block's SECOND
+                                   conv (3x3 s1 32->32 + BN + residual + ReLU; res_buf = the block input x, out_buf = y), the op
+                                   right before it -- kind ROMP_OP_NOP, every other field intact -- the FIRST (3x3 s1 32->32 + BN +
+                                   ReLU on x).  H2 tensors, f16x2 weights, H and W multiples of 16.  plan.py fuses the pairs.    */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 typedef struct romp_op {

@@ -169,9 +169,17 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(part && out && (op.res_buf == ROMP_BUF_NONE || res), "ksum: bad buffers %d -> %d", op.in_buf, op.out_buf);
             return launch_ksum(op, part, res, out, B, st);
         }
+        case ROMP_OP_BBLOCK32: {
+            ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP, "bblock32: the op before it must be the NOP holding the first conv");
+            const float* x = resolve_in(n, op.res_buf, image);
+            float* y = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(x && y && n->ops[idx - 1].in_buf == op.res_buf, "bblock32: bad buffers %d -> %d", op.res_buf, op.out_buf);
+            return launch_bblock32(n->ops[idx - 1], op, x, y, B, queue, st);
+        }
+        case ROMP_OP_NOP:
         case ROMP_OP_FORK:
         case ROMP_OP_JOIN:
-            return ROMP_OK;              // stream markers: handled by run_all
+            return ROMP_OK;              // stream markers: handled by run_all; NOP: fused into the next op
         default:
             set_error("unknown op kind %d", op.kind);
             return ROMP_EINVAL;
@@ -266,6 +274,12 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
     { const int rc = conv_init(); if (rc) return rc; }
+    for (int i = 0; i < n_ops; ++i)
+        if (ops_host[i].kind == ROMP_OP_BBLOCK32) {            // its one-time set-up (hipMalloc / attributes) must not run inside a stream capture
+            const int rc = launch_bblock32(ops_host[i], ops_host[i], nullptr, nullptr, 0, nullptr, nullptr);
+            if (rc) return rc;
+            break;
+        }
     romp_net* n = new romp_net();
     n->ops.assign(ops_host, ops_host + n_ops);
     n->buf_floats.assign(buf_floats, buf_floats + n_bufs);
@@ -563,7 +577,7 @@ int romp_net_range_scan(romp_net* n, const float* image, int B, float* center, f
     for (size_t i = 0; i < nops && rc == ROMP_OK; ++i) {
         rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, st);
         const romp_op& op = n->ops[i];
-        if (rc || op.out_buf < 0 || op.out_buf >= (int)n->bufs.size() || op.kind == ROMP_OP_FORK || op.kind == ROMP_OP_JOIN) continue;
+        if (rc || op.out_buf < 0 || op.out_buf >= (int)n->bufs.size() || op.kind == ROMP_OP_FORK || op.kind == ROMP_OP_JOIN || op.kind == ROMP_OP_NOP) continue;
         const size_t cnt = (size_t)n->buf_floats[op.out_buf] * B;
         const int h2 = op.out_fmt == ROMP_FMT_H2;
         hipLaunchKernelGGL(range_scan_kernel, dim3(1024), dim3(256), 0, st, n->bufs[op.out_buf], cnt, h2, ldexpf(1.f, -op.act_shift),
@@ -639,6 +653,8 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_KSUM) { snprintf(out, n, "ksum"); return ROMP_OK; }
     if (op->kind == ROMP_OP_STEM7) { snprintf(out, n, "stem7_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_MAXPOOL) { snprintf(out, n, "maxpool3s2"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_NOP) { snprintf(out, n, "nop"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_BBLOCK32) { snprintf(out, n, "bblock32"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BEV_PACK) { snprintf(out, n, "bev_pack"); return ROMP_OK; }

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OP_NOP, OP_BBLOCK32, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -266,6 +266,47 @@ def assign_formats(P):
                 op.term_fmt[role[1]] = fmt
 
 
+def fuse_basic_blocks(P):
+    """Peephole over the lowered program (after assign_formats): a 32-channel BasicBlock -- conv 3x3 s1 32->32 + BN + ReLU followed
+    by conv 3x3 s1 32->32 + BN + (block input) + ReLU, model.py:54-83 -- whose tensors are all H2 becomes ONE launch
+    (csrc/conv_h2b.hip: the intermediate tile stays in LDS): the first conv's op turns into ROMP_OP_NOP (fields intact: the
+    kernel takes its weights from there), the second into ROMP_OP_BBLOCK32.  Op indices, names and the flop / byte lists keep
+    their length; the pair's algorithmic bytes become x in + y out.  Batch plans only (a single-image plan has 64 tiles per
+    layer: a quarter of the CUs), env ROMP_FUSE_BLOCKS=0 switches it off (A/B runs).  -> number of fused blocks."""
+    import os
+    P.fused_blocks = 0
+    if not getattr(P, 'f16x2', False) or getattr(P, 'split_k_items', 0) or os.environ.get('ROMP_FUSE_BLOCKS', '1') == '0':
+        return 0
+    readers = {}
+    for i, op in enumerate(P.ops):
+        for b in [op.in_buf, op.res_buf] + [op.term_buf[k] for k in range(op.n_terms if op.kind == OP_FUSESUM else 0)]:
+            if b >= 0:
+                readers.setdefault(b, []).append(i)
+    for i in range(len(P.ops) - 1):
+        a, b = P.ops[i], P.ops[i + 1]
+        if not (a.kind == OP_CONV and b.kind == OP_CONV):
+            continue
+        plain = all(o.ksize == 3 and o.stride == 1 and o.groups == 1 and o.Cin == 32 and o.Cout == 32 and o.cin_pad == 32 and
+                    o.cout_pad == 32 and o.relu and o.weight_h2 and o.scale_h2 and o.pad_h == -1 and o.pad_w == -1 and
+                    o.out_rstride == 0 and o.out_bstride == 0 and o.H % 16 == 0 and o.W % 16 == 0 for o in (a, b))
+        chained = (a.res_buf < 0 and b.in_buf == a.out_buf and a.out_buf >= 0 and b.res_buf == a.in_buf and a.in_buf >= 0 and b.out_buf >= 0 and
+                   (b.res_cstride, b.res_coff) == (a.in_cstride, a.in_coff) and (b.in_cstride, b.in_coff) == (a.out_cstride, a.out_coff) and
+                   a.stream == b.stream and (a.H, a.W) == (b.H, b.W))
+        h2 = a.in_fmt == FMT_H2 and a.out_fmt == FMT_H2 and b.in_fmt == FMT_H2 and b.res_fmt == FMT_H2 and b.out_fmt == FMT_H2
+        # the intermediate tensor must die in the second conv: nobody else reads that live range of its buffer
+        later = [j for j in readers.get(a.out_buf, []) if j > i + 1]
+        writers_between = [j for j in range(i + 2, later[0] + 1) if P.ops[j].out_buf == a.out_buf] if later else [0]
+        private = not later or bool(writers_between)
+        if plain and chained and h2 and private and a.act_shift == b.act_shift:
+            a.kind, b.kind = OP_NOP, OP_BBLOCK32
+            P.flops[i + 1] += P.flops[i]
+            P.flops[i] = 0.0
+            P.bytes[i + 1] = 4.0 * a.H * a.W * 32 * 2
+            P.bytes[i] = 0.0
+            P.fused_blocks += 1
+    return P.fused_blocks
+
+
 class Program:
     """The lowered network: ops (ctypes), packed constants (kept alive here), buffer sizes."""
 
@@ -500,6 +541,7 @@ class Program:
 
     def op_array(self):
         assign_formats(self)
+        fuse_basic_blocks(self)
         arr = (RompOp * len(self.ops))()
         for i, o in enumerate(self.ops):
             arr[i] = o

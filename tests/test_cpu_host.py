@@ -288,7 +288,11 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM:
             written[op.out_buf] = op.out_fmt
-        elif op.kind not in (L.OP_FORK, L.OP_JOIN):
+        elif op.kind == L.OP_BBLOCK32:                       # fused BasicBlock: reads x (its residual buffer), writes y, both H2
+            assert written.get(op.res_buf) == L.FMT_H2 and op.res_fmt == L.FMT_H2 and op.out_fmt == L.FMT_H2, name
+            n_h2 += 1
+            written[op.out_buf] = op.out_fmt
+        elif op.kind not in (L.OP_FORK, L.OP_JOIN, L.OP_NOP):
             for b in (op.in_buf, op.res_buf):
                 assert b < 0 or written.get(b, L.FMT_F32) == L.FMT_F32, '%s (kind %d) would read an H2 tensor' % (name, op.kind)
             if op.out_buf >= 0:

@@ -336,6 +336,55 @@ def test_net_range_calibration(dev):
     assert bool(torch.isfinite(cm2).all()) and bool(torch.isfinite(pm2).all()), 'saturation, not inf / NaN'
 
 
+@pytest.mark.parametrize('B,H', [(1, 32), (3, 64), (2, 48)])
+def test_fused_basic_block32(dev, B, H):
+    """csrc/conv_h2b.hip: a 32-channel BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
+    ordinary conv producing the H2 block input, then the block -- lowered by plan.py (which must fuse the pair), run through
+    romp_net_create / romp_net_forward, against torch on the CPU: image borders (the intermediate's zero padding), interior
+    tiles, odd tile counts, batch > 1.  Same bound as the single layers, two layers deeper: 5e-5 of the output's magnitude."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math, decode_h2
+    g = torch.Generator().manual_seed(100 * B + H)
+    x = torch.randn(B, H, H, 32, generator=g)
+    ws = [torch.randn(32, 32, 3, 3, generator=g) / (32 * 9) ** 0.5 for _ in range(3)]
+    sc = [torch.rand(32, generator=g) + 0.5 for _ in range(3)]
+    sh = [torch.randn(32, generator=g) * 0.2 for _ in range(3)]
+
+    def cbr(t, i, res=None):
+        y = F.conv2d(t, ws[i], None, padding=1) * sc[i].view(1, -1, 1, 1) + sh[i].view(1, -1, 1, 1)
+        return torch.relu(y if res is None else y + res)
+    t0 = cbr(x.permute(0, 3, 1, 2), 0)
+    ref = cbr(cbr(t0, 1), 2, res=t0).permute(0, 2, 3, 1)
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    a0 = P.conv('c0', Act(L.BUF_IMAGE, 32, H, H, 32), [ws[0]], [sc[0]], [sh[0]], 3, 1, True)
+    a1 = P.conv('c1', a0, [ws[1]], [sc[1]], [sh[1]], 3, 1, True)
+    a2 = P.conv('c2', a1, [ws[2]], [sc[2]], [sh[2]], 3, 1, True, res=a0)
+    ops = P.op_array()
+    assert P.fused_blocks == 1 and [o.kind for o in P.ops] == [L.OP_CONV, L.OP_NOP, L.OP_BBLOCK32], [o.kind for o in P.ops]
+    assert P.ops[2].out_fmt == L.FMT_H2
+    lib = L.load()
+    h = C.c_void_p()
+    sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+    L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+    try:
+        xd = x.to(dev).contiguous()
+        dummy = torch.empty(16, device=dev)
+        n = P.buf_floats[a2.buf] * B
+        out = torch.empty(n, device=dev)
+        for rep in range(2):                                  # twice: the second run reuses warm buffers / queues
+            L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+            L.check(lib.romp_net_read_buffer(h, a2.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            y = decode_h2(out.cpu().reshape(B, H, H, 32))
+            err = (y - ref).abs().max().item() / ref.abs().max().item()
+            print(f'fused BasicBlock B={B} {H}x{H} run {rep}: relative err {err:.3e}')
+            assert err < 5e-5, err
+    finally:
+        lib.romp_net_destroy(h)
+
+
 def test_fusesum_formats(dev):
     """The fuse sum (model.py:233-244) with float32 and H2 terms / outputs gives the same values (the power-of-two scaling of
     the H2 format commutes with every rounding of the sum)."""
