@@ -31,8 +31,8 @@ struct BCfg {
     static constexpr int STAGE_BYTES = 4 * NI * 1024;          // 28 KiB (1600 units used), one per input chunk
     static constexpr int MID_PLANE = MR * RSU * 16;            // one 16-channel chunk of m: 23 040 bytes
     static constexpr int OFF_M = 2 * STAGE_BYTES;
-    static constexpr int OFF_E = OFF_M + 2 * MID_PLANE;        // epilogue staging tiles, one per wave
-    static constexpr int OFF_S = OFF_E + 4 * EPI_WAVE;         // [scale1 32 | shift1 32 | scale2 32 | shift2 32]
+    static constexpr int OFF_R = OFF_M + 2 * MID_PLANE;        // the tile's residual pieces, parked per lane: [wave][block][group][piece][lane] x 8 bytes
+    static constexpr int OFF_S = OFF_R + 4 * 2 * 4 * 2 * 64 * 8;  // [scale1 32 | shift1 32 | scale2 32 | shift2 32]
     static constexpr int LDS_BYTES = OFF_S + 128 * 4 + 16;
     static_assert(IR * RSU <= 4 * NI * 64, "stage pieces cover the input halo");
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -46,6 +46,9 @@ __device__ __forceinline__ int unit_of(int c, int w) { return (c >> 2) * 16 + (c
 
 // ConvParams as used here: in = x (H2), res = x, out = y (H2); w3 = conv1's split weights, wh = conv2's; scale = conv1's
 // f16x2 epilogue scale (32), w = conv1's shift (32, as floats), scale_h / shift = conv2's; the geometry fields as for a conv.
+// DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / residual parking, 4 no finish, 8 no MFMA,
+// 64 no fragment reads
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     using X = BCfg;
     using frag = f16x8;
@@ -59,15 +62,20 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    int tr_n = 0;                                              // phase stamps (ROMP_CONV_TRACE=1, scripts/bblock_bench.py): 1 entry, 4 set-up done,
+    constexpr int tr_wpw = 4;                                  // per tile 11 conv1 units, 13 hand-over tail, 12 barrier, 17 conv2 units, 14 finish tail, 15 barrier
+    ROMP_TRACE(1);
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int nwg_q = gridDim.x / p.n_queues;
     const int j0 = blockIdx.x / p.n_queues;
     if (j0 >= p.per_queue) return;
     const int n_mine = (p.per_queue - j0 + nwg_q - 1) / nwg_q;  // tiles of this workgroup: j0, j0 + nwg_q, ...
 
+    // scale / shift of both convs, PRE-MULTIPLIED by 2^act_shift: m and y are produced directly in the scaled domain the H2 pieces
+    // live in (ReLU commutes with the positive factor; the residual's pieces h1 + h2 are x * 2^act_shift already)
     if (tid < 128) {
         const float* src = tid < 32 ? p.scale : tid < 64 ? p.w : tid < 96 ? p.scale_h : p.shift;
-        sS[tid] = src[tid & 31];
+        sS[tid] = src[tid & 31] * p.act_scale;
     }
     // ---- the weights of both convs, all taps and both chunks, resident: lane (li, lh) = channel li, k-half lh
     frag w1[2][9][2], w2[2][9][2];
@@ -80,10 +88,11 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
                 w1[ch][tap][pc] = __builtin_bit_cast(frag, p.w3[(((tap * 2 + ch) * 2 + pc) * 2 + lh) * 32 + li]);
                 w2[ch][tap][pc] = __builtin_bit_cast(frag, p.wh[(((tap * 2 + ch) * 2 + pc) * 2 + lh) * 32 + li]);
             }
-    auto tile_of = [&](int k) { return decode_item(p, q, j0 + k * nwg_q, 32); };
+    auto tile_of = [&](int k) __attribute__((always_inline)) { return decode_item(p, q, j0 + k * nwg_q, 32); };
 
-    // DMA descriptors of this wave's pieces of one 16-channel input stage: (row, col, unit) of the 16-byte unit a lane fetches
-    int d_rc[X::NI];
+    // DMA pieces of this wave for one 16-channel input stage: the 16-byte unit a lane fetches -- its (row, col) in the 20x20 halo
+    // and its float offset from the halo origin
+    int d_rc[X::NI];                                           // row | col << 8 | inside << 16 | unit << 17
 #pragma unroll
     for (int k = 0; k < X::NI; ++k) {
         const int U = (k * 4 + wv) * 64 + lane;
@@ -92,62 +101,66 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
         const int col = cg * 4 + (r16 & 3), w = ((r16 >> 2) - cg) & 3;
         d_rc[k] = row | (col << 8) | ((row < X::IR) ? 1 << 16 : 0) | (w << 17);
     }
-    auto fetch_input = [&](int k) {                            // both chunks of tile k's 20x20 halo -> stage buffers 0 / 1
-        const bool valid = k < n_mine;
-        const Item it = tile_of(valid ? k : 0);
-        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co;
+    // piece kk of chunk ch of tile `it` (valid: is there such a tile) -> stage buffer ch.  Inline asm, not the builtin: hipcc
+    // guards every LDS read that follows a DMA it can see with a vmcnt wait (it cannot tell the buffers apart), which here
+    // would put the halo's whole memory latency in front of conv2's first fragment read.  Ordered by hand: vmcnt(0) + barrier
+    // at the end of the tile.
+    auto fetch_piece = [&](const Item& it, bool valid, int ch, int kk) __attribute__((always_inline)) {
+        if (DBG & 1) return;
+        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + ch * 16;
         const int iy0 = it.ty * X::TH - 2, ix0 = it.tx * X::TW - 2;
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int kk = 0; kk < X::NI; ++kk) {
-                int rc = d_rc[kk];
-                asm volatile("" : "+v"(rc));
-                const int row = rc & 255, col = (rc >> 8) & 255, w = (rc >> 17) & 3;
-                const int iy = iy0 + row, ix = ix0 + col;
-                const int ok = ((rc >> 16) & 1) & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)valid;
-                const unsigned long long a_in = (unsigned long long)(in + ((iy * p.W + ix) * p.in_cs + ch * 16 + w * 4));
-                const unsigned long long a = ok ? a_in : (unsigned long long)p.zero;
-                // Inline asm, not __builtin_amdgcn_global_load_lds: hipcc guards every LDS read that follows a DMA it can see with a
-                // vmcnt wait (it cannot tell the buffers apart) -- here the scale-table read of step 2, i.e. the halo's whole memory
-                // latency in front of conv2.  The fetch is ordered by hand instead: vmcnt(0) + barrier at the end of the tile.
-                const unsigned dst = lds0 + (unsigned)(ch * X::STAGE_BYTES + (kk * 4 + wv) * 1024);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(a), "s"(dst) : "memory");      // (m0 is reserved: hipcc keeps nothing in it; no other LDS-DMA / movrel here)
-            }
+        int rc = d_rc[kk];
+        asm volatile("" : "+v"(rc));                           // (opaque: keeps per-piece address parts out of the loop-invariant VGPRs)
+        const int iy = iy0 + (rc & 255), ix = ix0 + ((rc >> 8) & 255);
+        const int ok = ((rc >> 16) & 1) & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)valid;
+        const unsigned long long a_in = (unsigned long long)(in + ((iy * p.W + ix) * p.in_cs + ((rc >> 17) & 3) * 4));
+        const unsigned long long a = ok ? a_in : (unsigned long long)p.zero;
+        const unsigned dst = lds0 + (unsigned)(ch * X::STAGE_BYTES + (kk * 4 + wv) * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(a), "s"(dst) : "memory");
     };
     // conv1 block slots of this wave: blocks wv, wv + 4, wv + 8 of the 11 (slot 2 of wave 3 is idle).  Blocks 0-8: m rows 2b, 2b + 1,
     // m columns 1..16; block 9: m rows 0..15, columns {0, 17}; block 10: rows 16, 17, columns {0, 17} (4 lanes).
-    int my[3], mx[3];
-    bool act[3];
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
-        const int b = wv + 4 * sl;
-        if (b < 9) { my[sl] = 2 * b + li / 16; mx[sl] = 1 + li % 16; act[sl] = true; }
-        else if (b == 9) { my[sl] = li >> 1; mx[sl] = (li & 1) * 17; act[sl] = true; }
-        else if (b == 10) { my[sl] = li < 4 ? 16 + (li >> 1) : 0; mx[sl] = li < 4 ? (li & 1) * 17 : 0; act[sl] = li < 4; }
-        else { my[sl] = 0; mx[sl] = 0; act[sl] = false; }
+    // Slots 0 and 1 are always plain blocks 8 rows apart: slot 1's addresses are slot 0's plus a constant.
+    int myA, mxA, myC, mxC;                                    // m pixel of this lane in slots 0 (1: + 8 rows) and 2
+    bool actC;
+    {
+        myA = 2 * wv + li / 16; mxA = 1 + li % 16;
+        const int b = wv + 8;
+        if (b < 9) { myC = 2 * b + li / 16; mxC = 1 + li % 16; actC = true; }
+        else if (b == 9) { myC = li >> 1; mxC = (li & 1) * 17; actC = true; }
+        else if (b == 10) { myC = li < 4 ? 16 + (li >> 1) : 0; mxC = li < 4 ? (li & 1) * 17 : 0; actC = li < 4; }
+        else { myC = 0; mxC = 0; actC = false; }
     }
-    int xa[3][3][2];                                           // conv1: fragment address of input pixel (my, mx + dx), unit 2 lh + pc; + dy rows
+    int xaA[3][2], xaC[3][2];                                  // conv1: fragment address of input pixel (my, mx + dx), unit 2 lh + pc; + dy rows
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl)
+    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) xa[sl][dx][pc] = (my[sl] * X::RSU + unit_of(mx[sl] + dx, lh * 2 + pc)) * 16;
+        for (int pc = 0; pc < 2; ++pc) {
+            xaA[dx][pc] = (myA * X::RSU + unit_of(mxA + dx, lh * 2 + pc)) * 16;
+            xaC[dx][pc] = (myC * X::RSU + unit_of(mxC + dx, lh * 2 + pc)) * 16;
+        }
     int xa2[3][2];                                             // conv2: m pixel (4 wv + li / 16 + dy, li % 16 + dx); block j adds 2 rows
+    int ra2[2][2];                                             // the residual x of output pixel (4 wv + li / 16, li % 16) in the input halo: [octet-in-chunk][piece]
+    char* sR = sBuf + X::OFF_R + (wv * 1024 + lane) * 8;       // this lane's parking slots: + ((j * 4 + g4) * 2 + pc) * 512
     {
         const int prow = 4 * wv + li / 16, pcol = li % 16;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) xa2[dx][pc] = (prow * X::RSU + unit_of(pcol + dx, lh * 2 + pc)) * 16;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) ra2[o][pc] = ((prow + 2) * X::RSU + unit_of(pcol + 2, o * 2 + pc)) * 16 + lh * 8;
     }
-    char* sE = sBuf + X::OFF_E + wv * EPI_WAVE;
 
-    fetch_input(0);
-    // A "use" of every weight register in front of the tile loop: hipcc then waits for these loads HERE, once.  Left to the first
-    // MFMA inside the loop its wait is a conservative vmcnt(0) on every iteration -- in front of conv1 it would wait out the
-    // residual prefetch, in front of conv2 the halo DMA that is meant to fly under steps 3-4 (profiles/r03_h2r_notes.md).
+    Item it = tile_of(0);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, ch, kk);
+    // A "use" of every weight register in front of the tile loop: hipcc then waits for these loads HERE, once (left to the first
+    // MFMA inside the loop its wait is a conservative vmcnt(0) on every iteration)
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -155,114 +168,225 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             asm volatile("" :: "v"(w1[ch][tap][0]), "v"(w1[ch][tap][1]), "v"(w2[ch][tap][0]), "v"(w2[ch][tap][1]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                              // tile 0's halo and the scale table are in; weights in registers
+    ROMP_TRACE(4);
 
+    // one H2 value pair from two scaled float values: high pieces / low pieces as packed fp16 (v_cvt_pk_f16_f32: round to nearest even)
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    auto split2 = [&](float a, float b, unsigned& hi, unsigned& lo) __attribute__((always_inline)) {
+        const f32x2_t v = {h2_sat(a), h2_sat(b)};
+        const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+        const f32x2_t r = {v[0] - (float)h[0], v[1] - (float)h[1]};
+        const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, l);
+    };
+    const float* sS1 = sS + lh * 4;                            // this lane's channels of a group: 8 g4 + 4 lh .. + 3
+
+    // One wave per SIMD: nothing but this wave's OWN instructions can run in the shadow of its MFMAs, and the wave issues in
+    // order -- side work placed after a unit's three MFMAs runs after them, not under them (phase trace, round 3: 4 400 of a
+    // tile's 9 900 conv1 cycles).  So every kind of side work is cut into STEPS of <= ~8 VALU instructions (an MFMA is 32 cycles,
+    // a VALU instruction 4) and one step follows each MFMA, pinned there with a scheduling barrier.
+#define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
-        const Item it = tile_of(k);
-        EpiRes<2, 1> pre;                                      // the residual rows of this tile, in the epilogue's ownership
-        {
-            int lane_p = lane;
-            asm volatile("" : "+v"(lane_p));
-            conv_epilogue_prefetch<3, 1, 2, 1, 16, 16, 4>(p, it, wv, lane_p, pre);
-        }
-        // ---- 1. conv1: 27 block-steps per chunk, reads PF steps ahead
+        const bool has_next = k + 1 < n_mine;
+        const Item itn = has_next ? tile_of(k + 1) : it;
         f32x16 acc1[3];
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[sl][r] = 0.f;
+        // ---- side work of conv1 ------------------------------------------------------------------------------------------------
+        // (a) under slot 0: the residual pieces of this wave's output pixels go from the input halo to a per-lane parking area
+        //     (the halo buffers are refilled under conv2): copy i = (block, group, piece) is read at step 3 i, written at 3 i + 2
+        uint2 pk;
+        auto park_step = [&](int m) __attribute__((always_inline)) {
+            if (DBG & 2) return;
+            const int i = m / 3, w = m % 3;
+            if (i >= 16) return;
+            const int j = i / 8, g4 = (i % 8) / 2, pc = i % 2;
+            if (w == 0) pk = *reinterpret_cast<const uint2*>(sBuf + (g4 >> 1) * X::STAGE_BYTES + ra2[g4 & 1][pc] + 2 * j * (X::RSU * 16));
+            if (w == 2) *reinterpret_cast<uint2*>(sR + ((j * 4 + g4) * 2 + pc) * 512) = pk;
+        };
+        // (b) under slot s: the hand-over of slot s - 1 -- bn1 + ReLU (in the scaled domain), zero outside the image (conv2's
+        //     padding), split, into LDS as m.  Six steps per 4-channel group: table reads; values 0, 1; split; values 2, 3; split; store
+        f32x4 h_sc, h_sh;
+        float hv[4];
+        unsigned hh[2], ll[2];
+        bool h_in = false;
+        auto hand_step = [&](int sl, int t) __attribute__((always_inline)) {
+            if (DBG & 2) return;
+            const int g4 = t / 6, w = t % 6;
+            if (g4 >= 4) return;
+            const int my = sl == 2 ? myC : myA + 8 * sl, mx = sl == 2 ? mxC : mxA;
+            const bool act = sl == 2 ? actC : true;
+            if (w == 0) {
+                h_sc = *reinterpret_cast<const f32x4*>(sS1 + g4 * 8);
+                h_sh = *reinterpret_cast<const f32x4*>(sS1 + 32 + g4 * 8);
+                if (g4 == 0) {
+                    const int iy = it.ty * X::TH - 1 + my, ix = it.tx * X::TW - 1 + mx;
+                    h_in = act && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
+                }
+            } else if (w == 1 || w == 3) {
+#pragma unroll
+                for (int e = w - 1; e < w + 1; ++e) {
+                    const float a = fmaxf(fmaf(acc1[sl][g4 * 4 + e], h_sc[e], h_sh[e]), 0.f);
+                    hv[e] = h_in ? a : 0.f;
+                }
+            } else if (w == 2) {
+                split2(hv[0], hv[1], hh[0], ll[0]);
+            } else if (w == 4) {
+                split2(hv[2], hv[3], hh[1], ll[1]);
+            } else if (act) {                                  // channels 8 g4 + 4 lh ..: chunk g4 >> 1, octet-in-chunk g4 & 1, half lh of the unit
+                char* m = sM + (g4 >> 1) * X::MID_PLANE + lh * 8 + my * (X::RSU * 16);
+                *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 0) * 16) = make_uint2(hh[0], hh[1]);
+                *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 1) * 16) = make_uint2(ll[0], ll[1]);
+            }
+        };
+        // ---- 1. conv1, slot after slot
         {
-            constexpr int PF = 3, NU = 54;                     // unit u: chunk u / 27, tap (u % 27) / 3, slot u % 3
+            constexpr int PF = 2, NU = 54;                     // unit u: slot u / 18, chunk (u % 18) / 9, tap u % 9
             frag xf[PF + 1][2];
-            auto read_x = [&](int u) {
-                const int ch = u / 27, tap = (u % 27) / 3, sl = u % 3;
+            auto read_x = [&](int u) __attribute__((always_inline)) {
+                const int sl = u / 18, ch = (u % 18) / 9, tap = u % 9;
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc)
-                    xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + ch * X::STAGE_BYTES + xa[sl][tap % 3][pc] + (tap / 3) * (X::RSU * 16));
+                    xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + ch * X::STAGE_BYTES + (sl == 2 ? xaC : xaA)[tap % 3][pc] +
+                                                                          ((sl == 1 ? 8 : 0) + tap / 3) * (X::RSU * 16));
+            };
+            auto side = [&](int sl, int m) __attribute__((always_inline)) {
+                if (sl == 0) park_step(m); else hand_step(sl - 1, m);
+                SIDE_PIN();
             };
 #pragma unroll
             for (int u = 0; u < PF; ++u) read_x(u);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                const int ch = u / 27, tap = (u % 27) / 3, sl = u % 3;
-                if (u + PF < NU) read_x(u + PF);
+                const int sl = u / 18, ch = (u % 18) / 9, tap = u % 9, v = u % 18;
+                if (u + PF < NU && !((DBG & 64) && u > 2)) read_x(u + PF);
                 const frag (&x)[2] = xf[u % (PF + 1)];
-                acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ch][tap][1], x[0], acc1[sl], 0, 0, 0);
-                acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ch][tap][0], x[1], acc1[sl], 0, 0, 0);
-                acc1[sl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ch][tap][0], x[0], acc1[sl], 0, 0, 0);
-                if (u + PF < NU) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                f32x16& aa = acc1[sl];
+                f32x16& ab = acc1[sl];
+                if (!(DBG & 8)) aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ch][tap][1], x[0], aa, 0, 0, 0);
+                side(sl, v * 3 + 0);
+                if (!(DBG & 8)) ab = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ch][tap][0], x[1], ab, 0, 0, 0);
+                side(sl, v * 3 + 1);
+                if (!(DBG & 8)) aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ch][tap][0], x[0], aa, 0, 0, 0);
+                side(sl, v * 3 + 2);
             }
+            ROMP_TRACE(11);
+            if (DBG & 2) asm volatile("" :: "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]));   // (knock-out builds: keep the MFMAs)
+#pragma unroll
+            for (int t = 0; t < 24; ++t) hand_step(2, t);      // the last slot's: nothing left to hide it under
+            ROMP_TRACE(13);
         }
-        // ---- 2. every wave is done with the input halo: fetch the next tile's; hand m over
+        // ---- 2. every wave is done with the input halo and m is complete
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        fetch_input(k + 1);                                    // (the zero page beyond the last tile: the stream stays branch-free)
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            const int iy = it.ty * X::TH - 1 + my[sl], ix = it.tx * X::TW - 1 + mx[sl];
-            const bool inside = act[sl] && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int cl = g4 * 8 + lh * 4;
-                const float4 sc = *reinterpret_cast<const float4*>(sS + cl);
-                const float4 sh = *reinterpret_cast<const float4*>(sS + 32 + cl);
-                float4 v;
-                v.x = fmaxf(fmaf(acc1[sl][g4 * 4 + 0], sc.x, sh.x), 0.f);
-                v.y = fmaxf(fmaf(acc1[sl][g4 * 4 + 1], sc.y, sh.y), 0.f);
-                v.z = fmaxf(fmaf(acc1[sl][g4 * 4 + 2], sc.z, sh.z), 0.f);
-                v.w = fmaxf(fmaf(acc1[sl][g4 * 4 + 3], sc.w, sh.w), 0.f);
-                if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                uint2 hi, lo;
-                h2_pack(v, p.act_scale, hi, lo);
-                // channels 8 g4 + 4 lh ..: octet g4 = chunk g4 >> 1, octet-in-chunk g4 & 1; half lh of its high / low unit
-                char* m = sM + (g4 >> 1) * X::MID_PLANE + lh * 8;
-                if (act[sl]) {
-                    *reinterpret_cast<uint2*>(m + (my[sl] * X::RSU + unit_of(mx[sl], (g4 & 1) * 2 + 0)) * 16) = hi;
-                    *reinterpret_cast<uint2*>(m + (my[sl] * X::RSU + unit_of(mx[sl], (g4 & 1) * 2 + 1)) * 16) = lo;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // m is complete
-        // ---- 3. conv2 from m
-        f32x16 acc2[2][1];
+        ROMP_TRACE(12);
+        // ---- 3. conv2 from m, block after block.  Under block 0 the NEXT tile's halo is fetched: piece i's address at step 3 i, its
+        // DMA at step 3 i + 1.  Under block 1 block 0 is finished: bn2 + x + ReLU in the scaled domain, split; the two lanes of an
+        // octet trade halves (v_permlane32_swap) so that each stores one whole 16-byte unit.  Eight steps per 4-channel group.
+        f32x16 acc2[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[j][0][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+        unsigned long long f_a = 0;
+        auto fetch_step = [&](int m) __attribute__((always_inline)) {
+            if (DBG & 1) return;
+            const int i = m / 3, w = m % 3;
+            if (i >= 2 * X::NI || w == 2) return;
+            const int ch = i / X::NI, kk = i % X::NI;
+            if (w == 0) {
+                const float* in = p.in + (size_t)itn.b * p.H * p.W * p.in_cs + p.in_co + ch * 16;
+                int rc = d_rc[kk];
+                asm volatile("" : "+v"(rc));
+                const int iy = itn.ty * X::TH - 2 + (rc & 255), ix = itn.tx * X::TW - 2 + ((rc >> 8) & 255);
+                const int ok = ((rc >> 16) & 1) & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)has_next;
+                const unsigned long long a_in = (unsigned long long)(in + ((iy * p.W + ix) * p.in_cs + ((rc >> 17) & 3) * 4));
+                f_a = ok ? a_in : (unsigned long long)p.zero;
+            } else {
+                const unsigned dst = lds0 + (unsigned)(ch * X::STAGE_BYTES + (kk * 4 + wv) * 1024);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(f_a), "s"(dst) : "memory");
+            }
+        };
+        float* outp = p.out + (size_t)it.b * p.out_bs + p.out_co;
+        f32x4 e_sc, e_sh;
+        uint2 e_rh, e_rl;
+        float ev[4];
+        unsigned eh[2], el[2];
+        auto fin_step = [&](int j, int t) __attribute__((always_inline)) {                    // output pixel (4 wv + 2 j + li / 16, li % 16), channels 8 g4 + 4 lh .. + 3
+            if (DBG & 4) return;
+            const int g4 = t / 8, w = t % 8;
+            if (g4 >= 4) return;
+            if (w == 0) {
+                e_sc = *reinterpret_cast<const f32x4*>(sS1 + 64 + g4 * 8);
+                e_sh = *reinterpret_cast<const f32x4*>(sS1 + 96 + g4 * 8);
+                e_rh = *reinterpret_cast<const uint2*>(sR + ((j * 4 + g4) * 2 + 0) * 512);
+                e_rl = *reinterpret_cast<const uint2*>(sR + ((j * 4 + g4) * 2 + 1) * 512);
+            } else if (w == 1 || w == 2 || w == 4 || w == 5) {
+                const int e = w < 3 ? w - 1 : w - 2;
+                const f16x4 rh = __builtin_bit_cast(f16x4, e_rh), rl = __builtin_bit_cast(f16x4, e_rl);
+                ev[e] = fmaxf(fmaf(acc2[j][g4 * 4 + e], e_sc[e], e_sh[e]) + ((float)rh[e] + (float)rl[e]), 0.f);
+            } else if (w == 3) {
+                split2(ev[0], ev[1], eh[0], el[0]);
+            } else if (w == 6) {
+                split2(ev[2], ev[3], eh[1], el[1]);
+            } else {
+                // lanes L (channels .. + 0..3) and L + 32 (.. + 4..7): after the swaps L holds the octet's 8 high pieces, L + 32 its 8 low
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(eh[0], el[0], false, false);
+                const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(eh[1], el[1], false, false);
+                const int oy = it.ty * X::TH + 4 * wv + 2 * j + li / 16, ox = it.tx * X::TW + li % 16;
+                float* o = outp + ((unsigned)(oy * p.out_rs + ox * p.out_cs) + (unsigned)(g4 * 8 + lh * 4));
+                *reinterpret_cast<uint4*>(o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+        };
         {
-            constexpr int PF = 3, NU = 36;                     // unit u: chunk u / 18, tap (u % 18) / 2, block u % 2
+            constexpr int PF = 2, NU = 36;                     // unit u: block u / 18, chunk (u % 18) / 9, tap u % 9
             frag xf[PF + 1][2];
-            auto read_x = [&](int u) {
-                const int ch = u / 18, tap = (u % 18) / 2, j = u % 2;
+            auto read_x = [&](int u) __attribute__((always_inline)) {
+                const int j = u / 18, ch = (u % 18) / 9, tap = u % 9;
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc)
                     xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sM + ch * X::MID_PLANE + xa2[tap % 3][pc] + (2 * j + tap / 3) * (X::RSU * 16));
             };
+            auto side = [&](int j, int m) __attribute__((always_inline)) {
+                if (j == 0) fetch_step(m); else fin_step(0, m);
+                SIDE_PIN();
+            };
 #pragma unroll
             for (int u = 0; u < PF; ++u) read_x(u);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                const int ch = u / 18, tap = (u % 18) / 2, j = u % 2;
-                if (u + PF < NU) read_x(u + PF);
+                const int j = u / 18, ch = (u % 18) / 9, tap = u % 9, v = u % 18;
+                if (u + PF < NU && !((DBG & 64) && u > 2)) read_x(u + PF);
                 const frag (&x)[2] = xf[u % (PF + 1)];
-                acc2[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ch][tap][1], x[0], acc2[j][0], 0, 0, 0);
-                acc2[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ch][tap][0], x[1], acc2[j][0], 0, 0, 0);
-                acc2[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ch][tap][0], x[0], acc2[j][0], 0, 0, 0);
-                if (u + PF < NU) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                f32x16& aa = acc2[j];
+                f32x16& ab = acc2[j];
+                if (!(DBG & 8)) aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ch][tap][1], x[0], aa, 0, 0, 0);
+                side(j, v * 3 + 0);
+                if (!(DBG & 8)) ab = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ch][tap][0], x[1], ab, 0, 0, 0);
+                side(j, v * 3 + 1);
+                if (!(DBG & 8)) aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[ch][tap][0], x[0], aa, 0, 0, 0);
+                side(j, v * 3 + 2);
             }
+            ROMP_TRACE(17);
+            if (DBG & 4) asm volatile("" :: "v"(acc2[0]), "v"(acc2[1]));
+#pragma unroll
+            for (int t = 0; t < 32; ++t) fin_step(1, t);
+            ROMP_TRACE(14);
         }
-        // ---- 4. y tile: bn2 + x + ReLU, H2 stores (the ordinary fused epilogue, residual already in registers)
-        {
-            int lane_e = lane;
-            asm volatile("" : "+v"(lane_e));
-            conv_epilogue<3, 1, 2, 1, 16, 16, 4>(p, it, acc2, sS + 64, sE, wv, lane_e & 31, lane_e >> 5, pre, true);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next halo has landed (and this tile's stores are out)
-        __builtin_amdgcn_s_barrier();                          // ... for every wave; m may be overwritten
+        // ---- 4. the next halo has landed (and this tile's stores are out), for every wave; m may be overwritten
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ROMP_TRACE(15);
+        it = itn;
     }
+#undef SIDE_PIN
 }
 
 // `op` is the block's SECOND conv (its residual is the block input x, its output y); `op1` the first (weights / scale / shift).
@@ -279,8 +403,21 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     static bool attr = false;
     static float* zero = nullptr;                              // 256 bytes of zeros: what out-of-image lanes of the halo DMA fetch
     static int num_cu = 256;
+    using KernelFn = void (*)(ConvParams);
+    static KernelFn fn = bblock32_kernel<0>;
     if (!attr) {                                               // (romp_net_create calls this path's setup outside any stream capture: bblock_init)
-        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bblock32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
+        const char* e = getenv("ROMP_CONV_DEBUG");
+        switch (e ? atoi(e) : 0) {
+            case 0: break;
+            case 1: fn = bblock32_kernel<1>; break;
+            case 2: fn = bblock32_kernel<2>; break;
+            case 4: fn = bblock32_kernel<4>; break;
+            case 7: fn = bblock32_kernel<7>; break;
+            case 15: fn = bblock32_kernel<15>; break;
+            case 71: fn = bblock32_kernel<71>; break;
+            default: ROMP_REQUIRE(false, "bblock32: ROMP_CONV_DEBUG is one of 0 1 2 4 7 15 71 here");
+        }
+        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
         ROMP_HIP_CHECK(hipMalloc((void**)&zero, 256));
         ROMP_HIP_CHECK(hipMemset(zero, 0, 256));
         int dev = 0;
@@ -303,6 +440,7 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     p.inv_act_scale = ldexpf(1.f, -op.act_shift);
     p.in_h2 = p.out_h2 = p.res_h2 = 1;
     p.queue = queue;
+    p.trace = conv_trace_arm(st);
     p.H = p.Ho = op.H; p.W = p.Wo = op.W;
     p.Cout = 32; p.cin_valid = 32; p.cin_pad = 32; p.cout_pad = 32;
     p.in_cs = op1.in_cstride; p.in_co = op1.in_coff; p.in_gs = 0;
@@ -321,7 +459,7 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     long grid = num_cu;                                        // one workgroup per CU
     if (grid > p.tiles_total) grid = p.tiles_total;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(bblock32_kernel, dim3((unsigned)grid), dim3(256), BCfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), BCfg::LDS_BYTES, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

@@ -234,6 +234,17 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     return ROMP_OK;
 }
 
+// the (zeroed) stamp buffer for a kernel launched outside launch_conv (the fused BasicBlock), or nullptr when tracing is off
+unsigned long long* conv_trace_arm(hipStream_t st) {
+    if (!g_trace) {
+        const char* e = getenv("ROMP_CONV_TRACE");
+        if (!(e && atoi(e))) return nullptr;
+        if (hipMalloc((void**)&g_trace, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    }
+    if (hipMemsetAsync(g_trace, 0, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long), st) != hipSuccess) return nullptr;
+    return g_trace;
+}
+
 int conv_trace_read(unsigned long long* dst_host, int max_words) {
     ROMP_REQUIRE(g_trace != nullptr, "conv trace is off (set ROMP_CONV_TRACE=1 before the first launch)");
     const int n = max_words < TRACE_WAVES * TRACE_SLOTS ? max_words : TRACE_WAVES * TRACE_SLOTS;
