@@ -44,6 +44,33 @@ typedef const __attribute__((address_space(1))) void glb_void_b;
 // unit index of (column c, unit w of the 16-channel chunk) inside a row of RSU units (the rotated layout of conv_h2r.hip)
 __device__ __forceinline__ int unit_of(int c, int w) { return (c >> 2) * 16 + (c & 3) + 4 * ((w + (c >> 2)) & 3); }
 
+// Mixed-precision steps as ONE asm block each (v_fma_mix_f32 takes an fp16 operand as it is; hipcc turns `fma(ext(h), +-1, x)` into a
+// convert and an add, and follows every single-instruction asm whose result is used at once with an s_nop).
+// fp16x2 of (a - hi.x, b - hi.y): the low pieces of two values whose packed high pieces are `hi`
+__device__ __forceinline__ unsigned h2_low_pair(unsigned hi, float a, float b) {
+    unsigned lo;
+    float ta, tb;
+    asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2"
+        : "=v"(lo), "=&v"(ta), "=&v"(tb) : "v"(hi), "v"(a), "v"(b));
+    return lo;
+}
+// min(max(x + half HALF of rh + half HALF of rl, 0), top): the residual's two pieces, ReLU, saturation
+template <int HALF>
+__device__ __forceinline__ float add_pieces_relu(float x, unsigned rh, unsigned rl, float top) {
+    float d;
+    if (HALF == 0)
+        asm("v_fma_mix_f32 %0, %1, 1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_med3_f32 %0, %0, 0, %4" : "=&v"(d) : "v"(rh), "v"(rl), "v"(x), "v"(top));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_med3_f32 %0, %0, 0, %4" : "=&v"(d) : "v"(rh), "v"(rl), "v"(x), "v"(top));
+    return d;
+}
+
 // ConvParams as used here: in = x (H2), res = x, out = y (H2); w3 = conv1's split weights, wh = conv2's; scale = conv1's
 // f16x2 epilogue scale (32), w = conv1's shift (32, as floats), scale_h / shift = conv2's; the geometry fields as for a conv.
 // DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / residual parking, 4 no finish, 8 no MFMA,
@@ -63,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     int tr_n = 0;                                              // phase stamps (ROMP_CONV_TRACE=1, scripts/bblock_bench.py): 1 entry, 4 set-up done,
-    constexpr int tr_wpw = 4;                                  // per tile 11 conv1 units, 13 hand-over tail, 12 barrier, 17 conv2 units, 14 finish tail, 15 barrier
+    constexpr int tr_wpw = 4;                                  // per tile 11 conv1 units, 13 hand-over tail, 12 barrier, 17 conv2 units, 15 barrier
     ROMP_TRACE(1);
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
     const int nwg_q = gridDim.x / p.n_queues;
@@ -90,33 +117,48 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             }
     auto tile_of = [&](int k) __attribute__((always_inline)) { return decode_item(p, q, j0 + k * nwg_q, 32); };
 
-    // DMA pieces of this wave for one 16-channel input stage: the 16-byte unit a lane fetches -- its (row, col) in the 20x20 halo
-    // and its float offset from the halo origin
-    int d_rc[X::NI];                                           // row | col << 8 | inside << 16 | unit << 17
+    // DMA pieces of this wave for one 16-channel input stage (25 pieces of 64 units cover the 20 x 80 units exactly: piece 4 k + wv
+    // is this wave's k-th): the 16-byte unit a lane fetches -- its (row, col) in the 20x20 halo and its byte offset from the halo origin
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    int d_rc[X::NI], d_off[X::NI];                             // row | col << 8;  ((row * W + col) * in_cs + 4 unit) * 4
 #pragma unroll
     for (int k = 0; k < X::NI; ++k) {
         const int U = (k * 4 + wv) * 64 + lane;
         const int row = U / X::RSU, r = U % X::RSU;
         const int cg = r >> 4, r16 = r & 15;
         const int col = cg * 4 + (r16 & 3), w = ((r16 >> 2) - cg) & 3;
-        d_rc[k] = row | (col << 8) | ((row < X::IR) ? 1 << 16 : 0) | (w << 17);
+        d_rc[k] = row | (col << 8);
+        d_off[k] = ((row * p.W + col) * p.in_cs + w * 4) * 4;
     }
-    // piece kk of chunk ch of tile `it` (valid: is there such a tile) -> stage buffer ch.  Inline asm, not the builtin: hipcc
-    // guards every LDS read that follows a DMA it can see with a vmcnt wait (it cannot tell the buffers apart), which here
-    // would put the halo's whole memory latency in front of conv2's first fragment read.  Ordered by hand: vmcnt(0) + barrier
-    // at the end of the tile.
-    auto fetch_piece = [&](const Item& it, bool valid, int ch, int kk) __attribute__((always_inline)) {
+    // the input tensor as a raw buffer: a lane whose pixel is outside the image asks for an offset beyond num_records and gets zeros
+    i32x4_t rsrc;
+    {
+        const unsigned long long base = (unsigned long long)(p.in + p.in_co);
+        rsrc[0] = (int)(unsigned)base;
+        rsrc[1] = (int)(unsigned)(base >> 32) & 0xffff;
+        rsrc[2] = (int)((unsigned)p.in_bytes);
+        rsrc[3] = 0x00020000;
+    }
+    // piece kk of chunk ch of tile `it` -> stage buffer ch.  Inline asm, not the builtin: hipcc guards every LDS read that follows a DMA
+    // it can see with a vmcnt wait (it cannot tell the buffers apart), which here would put the halo's whole memory latency in front
+    // of conv2's first fragment read.  Ordered by hand: vmcnt(0) + barrier at the end of the tile.  An interior tile (no lane
+    // outside the image) costs an add, the M0 write and the DMA; an edge tile adds the per-lane test.
+    auto is_interior = [&](const Item& it) __attribute__((always_inline)) { return it.ty > 0 && it.ty < p.tiles_y - 1 && it.tx > 0 && it.tx < p.tiles_x - 1; };
+    auto fetch_piece = [&](const Item& it, bool valid, bool interior, int ch, int kk) __attribute__((always_inline)) {
         if (DBG & 1) return;
-        const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + ch * 16;
+        if (!valid || (kk == X::NI - 1 && wv != 0)) return;     // (uniform)
         const int iy0 = it.ty * X::TH - 2, ix0 = it.tx * X::TW - 2;
-        int rc = d_rc[kk];
-        asm volatile("" : "+v"(rc));                           // (opaque: keeps per-piece address parts out of the loop-invariant VGPRs)
-        const int iy = iy0 + (rc & 255), ix = ix0 + ((rc >> 8) & 255);
-        const int ok = ((rc >> 16) & 1) & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)valid;
-        const unsigned long long a_in = (unsigned long long)(in + ((iy * p.W + ix) * p.in_cs + ((rc >> 17) & 3) * 4));
-        const unsigned long long a = ok ? a_in : (unsigned long long)p.zero;
+        const int origin = (((it.b * p.H + iy0) * p.W + ix0) * p.in_cs + ch * 16) * 4;    // may be "negative": the sum with d_off is not
         const unsigned dst = lds0 + (unsigned)(ch * X::STAGE_BYTES + (kk * 4 + wv) * 1024);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(a), "s"(dst) : "memory");
+        int voff = d_off[kk] + origin;
+        if (!interior) {
+            int rc = d_rc[kk];
+            asm volatile("" : "+v"(rc));                       // (opaque: keeps per-piece address parts out of the loop-invariant VGPRs)
+            const int iy = iy0 + (rc & 255), ix = ix0 + (rc >> 8);
+            const int ok = (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
+            voff = ok ? voff : (int)0x80000000;
+        }
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(dst) : "memory");
     };
     // conv1 block slots of this wave: blocks wv, wv + 4, wv + 8 of the 11 (slot 2 of wave 3 is idle).  Blocks 0-8: m rows 2b, 2b + 1,
     // m columns 1..16; block 9: m rows 0..15, columns {0, 17}; block 10: rows 16, 17, columns {0, 17} (4 lanes).
@@ -158,14 +200,14 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, ch, kk);
+        for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, ch, kk);
     // A "use" of every weight register in front of the tile loop: hipcc then waits for these loads HERE, once (left to the first
     // MFMA inside the loop its wait is a conservative vmcnt(0) on every iteration)
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
-            asm volatile("" :: "v"(w1[ch][tap][0]), "v"(w1[ch][tap][1]), "v"(w2[ch][tap][0]), "v"(w2[ch][tap][1]));
+            asm volatile("" : "+a"(w1[ch][tap][0]), "+a"(w1[ch][tap][1]), "+v"(w2[ch][tap][0]), "+v"(w2[ch][tap][1]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                              // tile 0's halo and the scale table are in; weights in registers
     ROMP_TRACE(4);
@@ -182,6 +224,14 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
         hi = __builtin_bit_cast(unsigned, h);
         lo = __builtin_bit_cast(unsigned, l);
     };
+    // the same in two micro-steps: (a, b) -> hi;  -> lo = fp16(a - hi.x), fp16(b - hi.y)
+    auto split_a = [&](float a, float b, unsigned& hi) __attribute__((always_inline)) {
+        const f32x2_t v = {a, b};
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+    };
+    auto split_b = [&](float a, float b, unsigned hi, unsigned& lo) __attribute__((always_inline)) {
+        lo = h2_low_pair(hi, a, b);
+    };
     const float* sS1 = sS + lh * 4;                            // this lane's channels of a group: 8 g4 + 4 lh .. + 3
 
     // One wave per SIMD: nothing but this wave's OWN instructions can run in the shadow of its MFMAs, and the wave issues in
@@ -189,61 +239,133 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     // tile's 9 900 conv1 cycles).  So every kind of side work is cut into STEPS of <= ~8 VALU instructions (an MFMA is 32 cycles,
     // a VALU instruction 4) and one step follows each MFMA, pinned there with a scheduling barrier.
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
+    f32x16 acc2[2];                                            // (block 1's outlives its tile: finished under the next tile's conv1)
+    Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
         const bool has_next = k + 1 < n_mine;
         const Item itn = has_next ? tile_of(k + 1) : it;
+        const bool next_interior = is_interior(itn);
         f32x16 acc1[3];
 #pragma unroll
         for (int sl = 0; sl < 3; ++sl)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[sl][r] = 0.f;
+        // ---- the finish of a conv2 block: bn2 + x + ReLU in the scaled domain, split; the two lanes of an octet trade halves
+        // (v_permlane32_swap) so that each stores one whole 16-byte unit.  Eight steps per 4-channel group.  Block 0 is finished
+        // under block 1's MFMAs, block 1 under slot 0 of the NEXT tile's conv1 (`tl` is then the previous tile; `live`: there is one).
+        f32x4 e_sc, e_sh;
+        uint2 e_rh, e_rl;
+        float ev[4];
+        unsigned eh[2], el[2];
+        int e_o = 0;
+        constexpr int FIN_N = 4 + 4 * 15;
+        auto fin_micro = [&](const Item& tl, bool live, int j, int t) __attribute__((always_inline)) {   // output pixel (4 wv + 2 j + li / 16, li % 16), channels 8 g4 + 4 lh .. + 3
+            if (DBG & 4) return;
+            auto prep = [&](int g4) __attribute__((always_inline)) {      // (an LDS round trip ahead of its first use: micro-steps 1-3 are empty)
+                e_sc = *reinterpret_cast<const f32x4*>(sS1 + 64 + g4 * 8);
+                e_sh = *reinterpret_cast<const f32x4*>(sS1 + 96 + g4 * 8);
+                e_rh = *reinterpret_cast<const uint2*>(sR + ((j * 4 + g4) * 2 + 0) * 512);
+                e_rl = *reinterpret_cast<const uint2*>(sR + ((j * 4 + g4) * 2 + 1) * 512);
+            };
+            if (t < 4) { if (t == 0) prep(0); return; }
+            const int g4 = (t - 4) / 15, w = (t - 4) % 15;
+            switch (w) {
+            case 0: case 2: case 6: case 8: {                  // value e, first half: bn2
+                const int e = w == 0 ? 0 : w == 2 ? 1 : w == 6 ? 2 : 3;
+                ev[e] = fmaf(acc2[j][g4 * 4 + e], e_sc[e], e_sh[e]);
+                break; }
+            case 1: case 3: case 7: case 9: {                  // second half: + the residual's two pieces, ReLU, saturate
+                const int e = w == 1 ? 0 : w == 3 ? 1 : w == 7 ? 2 : 3;
+                const unsigned wh = e < 2 ? e_rh.x : e_rh.y, wl = e < 2 ? e_rl.x : e_rl.y;
+                ev[e] = (e & 1) ? add_pieces_relu<1>(ev[e], wh, wl, H2_MAX) : add_pieces_relu<0>(ev[e], wh, wl, H2_MAX);
+                if (w == 9 && g4 < 3) prep(g4 + 1);            // the tables are free: the next group's reads go out now
+                break; }
+            case 4: split_a(ev[0], ev[1], eh[0]); break;
+            case 5: split_b(ev[0], ev[1], eh[0], el[0]); break;
+            case 10: split_a(ev[2], ev[3], eh[1]); break;
+            case 11: split_b(ev[2], ev[3], eh[1], el[1]); break;
+            case 12: {
+                // lanes L (channels .. + 0..3) and L + 32 (.. + 4..7): after the swaps L holds the octet's 8 high pieces, L + 32 its 8 low
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(eh[0], el[0], false, false);
+                const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(eh[1], el[1], false, false);
+                eh[0] = s0[0]; el[0] = s0[1]; eh[1] = s1[0]; el[1] = s1[1];
+                break; }
+            case 13: {
+                const int oy = tl.ty * X::TH + 4 * wv + 2 * j + li / 16, ox = tl.tx * X::TW + li % 16;
+                e_o = (oy * p.out_rs + ox * p.out_cs) + (g4 * 8 + lh * 4);
+                break; }
+            default: {
+                float* o = p.out + (size_t)tl.b * p.out_bs + p.out_co + (unsigned)e_o;
+                if (live) *reinterpret_cast<uint4*>(o) = make_uint4(eh[0], eh[1], el[0], el[1]);
+                break; }
+            }
+        };
         // ---- side work of conv1 ------------------------------------------------------------------------------------------------
-        // (a) under slot 0: the residual pieces of this wave's output pixels go from the input halo to a per-lane parking area
-        //     (the halo buffers are refilled under conv2): copy i = (block, group, piece) is read at step 3 i, written at 3 i + 2
-        uint2 pk;
-        auto park_step = [&](int m) __attribute__((always_inline)) {
+        // (a) under slot 0, after the previous tile's finish: the residual pieces of this wave's output pixels go from the input
+        //     halo to a per-lane parking area (the halo buffers are refilled under conv2): copy i = (block, group, piece) is read
+        //     at step 32 + i and written two steps later
+        uint2 pk[4];
+        constexpr int PARK_N = 32;
+        auto park_micro = [&](int t) __attribute__((always_inline)) {       // r0 r1 r2 | w0 r3 | w1 r4 | ... | w12 r15 | w13 w14 w15
             if (DBG & 2) return;
-            const int i = m / 3, w = m % 3;
-            if (i >= 16) return;
-            const int j = i / 8, g4 = (i % 8) / 2, pc = i % 2;
-            if (w == 0) pk = *reinterpret_cast<const uint2*>(sBuf + (g4 >> 1) * X::STAGE_BYTES + ra2[g4 & 1][pc] + 2 * j * (X::RSU * 16));
-            if (w == 2) *reinterpret_cast<uint2*>(sR + ((j * 4 + g4) * 2 + pc) * 512) = pk;
+            auto rd = [&](int i) __attribute__((always_inline)) {
+                const int j = i / 8, g4 = (i % 8) / 2, pc = i % 2;
+                pk[i % 4] = *reinterpret_cast<const uint2*>(sBuf + (g4 >> 1) * X::STAGE_BYTES + ra2[g4 & 1][pc] + 2 * j * (X::RSU * 16));
+            };
+            auto wr = [&](int i) __attribute__((always_inline)) { *reinterpret_cast<uint2*>(sR + i * 512) = pk[i % 4]; };
+            if (t < 3) rd(t);
+            else if (t < 29) { if ((t - 3) % 2 == 0) wr((t - 3) / 2); else rd((t - 3) / 2 + 3); }
+            else wr(13 + (t - 29));
         };
         // (b) under slot s: the hand-over of slot s - 1 -- bn1 + ReLU (in the scaled domain), zero outside the image (conv2's
-        //     padding), split, into LDS as m.  Six steps per 4-channel group: table reads; values 0, 1; split; values 2, 3; split; store
+        //     padding), split, into LDS as m.  Micro-steps 0-3: the first group's table reads, is this lane's pixel inside the
+        //     image, two empty; then ten per 4-channel group: values 0, 1; split (2); values 2, 3 (+ the next group's table reads);
+        //     split (2); the two stores
         f32x4 h_sc, h_sh;
         float hv[4];
         unsigned hh[2], ll[2];
         bool h_in = false;
-        auto hand_step = [&](int sl, int t) __attribute__((always_inline)) {
+        constexpr int HAND_N = 4 + 4 * 10;
+        auto hand_micro = [&](int sl, int t) __attribute__((always_inline)) {
             if (DBG & 2) return;
-            const int g4 = t / 6, w = t % 6;
-            if (g4 >= 4) return;
             const int my = sl == 2 ? myC : myA + 8 * sl, mx = sl == 2 ? mxC : mxA;
             const bool act = sl == 2 ? actC : true;
-            if (w == 0) {
+            auto prep = [&](int g4) __attribute__((always_inline)) {      // (an LDS round trip ahead of its first use)
                 h_sc = *reinterpret_cast<const f32x4*>(sS1 + g4 * 8);
                 h_sh = *reinterpret_cast<const f32x4*>(sS1 + 32 + g4 * 8);
-                if (g4 == 0) {
+            };
+            if (t < 4) {
+                if (t == 0) prep(0);
+                if (t == 1) {
                     const int iy = it.ty * X::TH - 1 + my, ix = it.tx * X::TW - 1 + mx;
                     h_in = act && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
                 }
-            } else if (w == 1 || w == 3) {
-#pragma unroll
-                for (int e = w - 1; e < w + 1; ++e) {
-                    const float a = fmaxf(fmaf(acc1[sl][g4 * 4 + e], h_sc[e], h_sh[e]), 0.f);
-                    hv[e] = h_in ? a : 0.f;
-                }
-            } else if (w == 2) {
-                split2(hv[0], hv[1], hh[0], ll[0]);
-            } else if (w == 4) {
-                split2(hv[2], hv[3], hh[1], ll[1]);
-            } else if (act) {                                  // channels 8 g4 + 4 lh ..: chunk g4 >> 1, octet-in-chunk g4 & 1, half lh of the unit
-                char* m = sM + (g4 >> 1) * X::MID_PLANE + lh * 8 + my * (X::RSU * 16);
-                *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 0) * 16) = make_uint2(hh[0], hh[1]);
-                *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 1) * 16) = make_uint2(ll[0], ll[1]);
+                return;
             }
+            const int g4 = (t - 4) / 10, w = (t - 4) % 10;
+            char* m = sM + (g4 >> 1) * X::MID_PLANE + lh * 8 + my * (X::RSU * 16);   // channels 8 g4 + 4 lh ..: chunk g4 >> 1, octet-in-chunk g4 & 1, half lh of the unit
+            switch (w) {
+            case 0: case 1: case 4: case 5: {
+                const int e = w < 2 ? w : w - 2;
+                const float a = h2_sat(fmaxf(fmaf(acc1[sl][g4 * 4 + e], h_sc[e], h_sh[e]), 0.f));
+                hv[e] = h_in ? a : 0.f;
+                if (w == 5 && g4 < 3) prep(g4 + 1);            // the tables are free: the next group's reads go out now
+                break; }
+            case 2: split_a(hv[0], hv[1], hh[0]); break;
+            case 3: split_b(hv[0], hv[1], hh[0], ll[0]); break;
+            case 6: split_a(hv[2], hv[3], hh[1]); break;
+            case 7: split_b(hv[2], hv[3], hh[1], ll[1]); break;
+            case 8: if (act) *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 0) * 16) = make_uint2(hh[0], hh[1]); break;
+            default: if (act) *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 1) * 16) = make_uint2(ll[0], ll[1]); break;
+            }
+        };
+        // Micro-steps [lo, hi) of a phase's N for step m of a block's 54: spread evenly, the step in front of a unit's fragment
+        // reads (every third) taking half a share
+        auto share = [](int m, int N, int& lo, int& hi) __attribute__((always_inline)) {
+            const int c0 = (m / 3) * 5 + (m % 3) * 2, c1 = ((m + 1) / 3) * 5 + ((m + 1) % 3) * 2;
+            lo = c0 * N / 90; hi = c1 * N / 90;
         };
         // ---- 1. conv1, slot after slot
         {
@@ -257,7 +379,17 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
                                                                           ((sl == 1 ? 8 : 0) + tap / 3) * (X::RSU * 16));
             };
             auto side = [&](int sl, int m) __attribute__((always_inline)) {
-                if (sl == 0) park_step(m); else hand_step(sl - 1, m);
+                int lo, hi;
+                if (sl == 0) {                                 // the previous tile's second block
+                    share(m, FIN_N, lo, hi);
+#pragma unroll
+                    for (int t = lo; t < hi; ++t) fin_micro(itp, k > 0, 1, t);
+                } else {                                       // slot 1 also parks this tile's residual
+                    const int N = HAND_N + (sl == 1 ? PARK_N : 0);
+                    share(m, N, lo, hi);
+#pragma unroll
+                    for (int t = lo; t < hi; ++t) { if (t < HAND_N) hand_micro(sl - 1, t); else park_micro(t - HAND_N); }
+                }
                 SIDE_PIN();
             };
 #pragma unroll
@@ -279,71 +411,21 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             ROMP_TRACE(11);
             if (DBG & 2) asm volatile("" :: "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]));   // (knock-out builds: keep the MFMAs)
 #pragma unroll
-            for (int t = 0; t < 24; ++t) hand_step(2, t);      // the last slot's: nothing left to hide it under
+            for (int t = 0; t < HAND_N; ++t) hand_micro(2, t); // the last slot's: nothing left to hide it under
             ROMP_TRACE(13);
         }
         // ---- 2. every wave is done with the input halo and m is complete
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ROMP_TRACE(12);
-        // ---- 3. conv2 from m, block after block.  Under block 0 the NEXT tile's halo is fetched: piece i's address at step 3 i, its
-        // DMA at step 3 i + 1.  Under block 1 block 0 is finished: bn2 + x + ReLU in the scaled domain, split; the two lanes of an
+        // ---- 3. conv2 from m, block after block.  Under block 0 the NEXT tile's halo is fetched, a DMA piece every fourth step.  Under block 1 block 0 is finished: bn2 + x + ReLU in the scaled domain, split; the two lanes of an
         // octet trade halves (v_permlane32_swap) so that each stores one whole 16-byte unit.  Eight steps per 4-channel group.
-        f32x16 acc2[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-        unsigned long long f_a = 0;
-        auto fetch_step = [&](int m) __attribute__((always_inline)) {
-            if (DBG & 1) return;
-            const int i = m / 3, w = m % 3;
-            if (i >= 2 * X::NI || w == 2) return;
-            const int ch = i / X::NI, kk = i % X::NI;
-            if (w == 0) {
-                const float* in = p.in + (size_t)itn.b * p.H * p.W * p.in_cs + p.in_co + ch * 16;
-                int rc = d_rc[kk];
-                asm volatile("" : "+v"(rc));
-                const int iy = itn.ty * X::TH - 2 + (rc & 255), ix = itn.tx * X::TW - 2 + ((rc >> 8) & 255);
-                const int ok = ((rc >> 16) & 1) & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)has_next;
-                const unsigned long long a_in = (unsigned long long)(in + ((iy * p.W + ix) * p.in_cs + ((rc >> 17) & 3) * 4));
-                f_a = ok ? a_in : (unsigned long long)p.zero;
-            } else {
-                const unsigned dst = lds0 + (unsigned)(ch * X::STAGE_BYTES + (kk * 4 + wv) * 1024);
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(f_a), "s"(dst) : "memory");
-            }
-        };
-        float* outp = p.out + (size_t)it.b * p.out_bs + p.out_co;
-        f32x4 e_sc, e_sh;
-        uint2 e_rh, e_rl;
-        float ev[4];
-        unsigned eh[2], el[2];
-        auto fin_step = [&](int j, int t) __attribute__((always_inline)) {                    // output pixel (4 wv + 2 j + li / 16, li % 16), channels 8 g4 + 4 lh .. + 3
-            if (DBG & 4) return;
-            const int g4 = t / 8, w = t % 8;
-            if (g4 >= 4) return;
-            if (w == 0) {
-                e_sc = *reinterpret_cast<const f32x4*>(sS1 + 64 + g4 * 8);
-                e_sh = *reinterpret_cast<const f32x4*>(sS1 + 96 + g4 * 8);
-                e_rh = *reinterpret_cast<const uint2*>(sR + ((j * 4 + g4) * 2 + 0) * 512);
-                e_rl = *reinterpret_cast<const uint2*>(sR + ((j * 4 + g4) * 2 + 1) * 512);
-            } else if (w == 1 || w == 2 || w == 4 || w == 5) {
-                const int e = w < 3 ? w - 1 : w - 2;
-                const f16x4 rh = __builtin_bit_cast(f16x4, e_rh), rl = __builtin_bit_cast(f16x4, e_rl);
-                ev[e] = fmaxf(fmaf(acc2[j][g4 * 4 + e], e_sc[e], e_sh[e]) + ((float)rh[e] + (float)rl[e]), 0.f);
-            } else if (w == 3) {
-                split2(ev[0], ev[1], eh[0], el[0]);
-            } else if (w == 6) {
-                split2(ev[2], ev[3], eh[1], el[1]);
-            } else {
-                // lanes L (channels .. + 0..3) and L + 32 (.. + 4..7): after the swaps L holds the octet's 8 high pieces, L + 32 its 8 low
-                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(eh[0], el[0], false, false);
-                const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(eh[1], el[1], false, false);
-                const int oy = it.ty * X::TH + 4 * wv + 2 * j + li / 16, ox = it.tx * X::TW + li % 16;
-                float* o = outp + ((unsigned)(oy * p.out_rs + ox * p.out_cs) + (unsigned)(g4 * 8 + lh * 4));
-                *reinterpret_cast<uint4*>(o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-            }
+        auto fetch_step = [&](int m) __attribute__((always_inline)) {      // piece i at step 4 i + 1 of block 0
+            if (m % 4 == 1 && m / 4 < 2 * X::NI) fetch_piece(itn, has_next, next_interior, (m / 4) / X::NI, (m / 4) % X::NI);
         };
         {
             constexpr int PF = 2, NU = 36;                     // unit u: block u / 18, chunk (u % 18) / 9, tap u % 9
@@ -355,7 +437,13 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
                     xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sM + ch * X::MID_PLANE + xa2[tap % 3][pc] + (2 * j + tap / 3) * (X::RSU * 16));
             };
             auto side = [&](int j, int m) __attribute__((always_inline)) {
-                if (j == 0) fetch_step(m); else fin_step(0, m);
+                if (j == 0) fetch_step(m);
+                else {
+                    int lo, hi;
+                    share(m, FIN_N, lo, hi);
+#pragma unroll
+                    for (int t = lo; t < hi; ++t) fin_micro(it, true, 0, t);
+                }
                 SIDE_PIN();
             };
 #pragma unroll
@@ -376,15 +464,34 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             }
             ROMP_TRACE(17);
             if (DBG & 4) asm volatile("" :: "v"(acc2[0]), "v"(acc2[1]));
-#pragma unroll
-            for (int t = 0; t < 32; ++t) fin_step(1, t);
-            ROMP_TRACE(14);
         }
         // ---- 4. the next halo has landed (and this tile's stores are out), for every wave; m may be overwritten
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ROMP_TRACE(15);
+        itp = it;
         it = itn;
+    }
+    if (!(DBG & 4)) {                                          // the last tile's second block
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 e_sc = *reinterpret_cast<const f32x4*>(sS1 + 64 + g4 * 8);
+            const f32x4 e_sh = *reinterpret_cast<const f32x4*>(sS1 + 96 + g4 * 8);
+            const f16x4 rh = __builtin_bit_cast(f16x4, *reinterpret_cast<const uint2*>(sR + ((4 + g4) * 2 + 0) * 512));
+            const f16x4 rl = __builtin_bit_cast(f16x4, *reinterpret_cast<const uint2*>(sR + ((4 + g4) * 2 + 1) * 512));
+            float ev[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ev[e] = fmaxf(fmaf(acc2[1][g4 * 4 + e], e_sc[e], e_sh[e]) + ((float)rh[e] + (float)rl[e]), 0.f);
+            unsigned eh[2], el[2];
+            split2(ev[0], ev[1], eh[0], el[0]);
+            split2(ev[2], ev[3], eh[1], el[1]);
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(eh[0], el[0], false, false);
+            const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(eh[1], el[1], false, false);
+            const int oy = itp.ty * X::TH + 4 * wv + 2 + li / 16, ox = itp.tx * X::TW + li % 16;
+            float* o = p.out + (size_t)itp.b * p.out_bs + p.out_co + ((unsigned)(oy * p.out_rs + ox * p.out_cs) + (unsigned)(g4 * 8 + lh * 4));
+            *reinterpret_cast<uint4*>(o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
     }
 #undef SIDE_PIN
 }
@@ -413,9 +520,10 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
             case 2: fn = bblock32_kernel<2>; break;
             case 4: fn = bblock32_kernel<4>; break;
             case 7: fn = bblock32_kernel<7>; break;
+            case 8: fn = bblock32_kernel<8>; break;
             case 15: fn = bblock32_kernel<15>; break;
             case 71: fn = bblock32_kernel<71>; break;
-            default: ROMP_REQUIRE(false, "bblock32: ROMP_CONV_DEBUG is one of 0 1 2 4 7 15 71 here");
+            default: ROMP_REQUIRE(false, "bblock32: ROMP_CONV_DEBUG is one of 0 1 2 4 7 8 15 71 here");
         }
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
         ROMP_HIP_CHECK(hipMalloc((void**)&zero, 256));
@@ -441,6 +549,11 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     p.in_h2 = p.out_h2 = p.res_h2 = 1;
     p.queue = queue;
     p.trace = conv_trace_arm(st);
+    {
+        const unsigned long long bytes = ((unsigned long long)B * op.H * op.W * op1.in_cstride - op1.in_coff) * 4ull;
+        ROMP_REQUIRE(bytes < 0x80000000ull, "bblock32: input tensor of %llu bytes: beyond the 31-bit offsets of the halo fetch", bytes);
+        p.in_bytes = (unsigned)bytes;
+    }
     p.H = p.Ho = op.H; p.W = p.Wo = op.W;
     p.Cout = 32; p.cin_valid = 32; p.cin_pad = 32; p.cout_pad = 32;
     p.in_cs = op1.in_cstride; p.in_co = op1.in_coff; p.in_gs = 0;
