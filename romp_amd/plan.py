@@ -540,8 +540,13 @@ class Program:
         return out
 
     def op_array(self):
-        assign_formats(self)
-        fuse_basic_blocks(self)
+        """The lowered op list as a ctypes array.  Lowering (tensor formats, block fusion) happens on the first call; later calls
+        (export.save_plan on a program its net already created) return the same ops -- the format pass reads conv kinds and
+        must not see the fused ones."""
+        if not getattr(self, '_lowered', False):
+            assign_formats(self)
+            fuse_basic_blocks(self)
+            self._lowered = True
         arr = (RompOp * len(self.ops))()
         for i, o in enumerate(self.ops):
             arr[i] = o

@@ -269,6 +269,9 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
         sd = S.make_resnet_state_dict(0)
     P = build(sd, 'cpu', 512, bf16x3='f16x2')
     P.op_array()
+    lowered = [(op.kind, op.in_fmt, op.res_fmt, op.out_fmt) for op in P.ops]
+    P.op_array()                                             # (export.save_plan asks again: the lowering must not run twice)
+    assert lowered == [(op.kind, op.in_fmt, op.res_fmt, op.out_fmt) for op in P.ops]
     buf = C.create_string_buffer(128)
     written = {}
     n_h2 = 0
