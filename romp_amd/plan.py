@@ -271,11 +271,12 @@ def fuse_basic_blocks(P):
     by conv 3x3 s1 32->32 + BN + (block input) + ReLU, model.py:54-83 -- whose tensors are all H2 becomes ONE launch
     (csrc/conv_h2b.hip: the intermediate tile stays in LDS): the first conv's op turns into ROMP_OP_NOP (fields intact: the
     kernel takes its weights from there), the second into ROMP_OP_BBLOCK32.  Op indices, names and the flop / byte lists keep
-    their length; the pair's algorithmic bytes become x in + y out.  Batch plans only (a single-image plan has 64 tiles per
-    layer: a quarter of the CUs), env ROMP_FUSE_BLOCKS=0 switches it off (A/B runs).  -> number of fused blocks."""
+    their length; the pair's algorithmic bytes become x in + y out.  Single-image plans too (64 tiles there, a quarter of the
+    CUs, but 32 fewer launches on a launch-bound chain: network 2.15 -> 1.95 ms at B = 1); env ROMP_FUSE_BLOCKS=0 switches it
+    off (A/B runs).  -> number of fused blocks."""
     import os
     P.fused_blocks = 0
-    if not getattr(P, 'f16x2', False) or getattr(P, 'split_k_items', 0) or os.environ.get('ROMP_FUSE_BLOCKS', '1') == '0':
+    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_BLOCKS', '1') == '0':
         return 0
     readers = {}
     for i, op in enumerate(P.ops):
