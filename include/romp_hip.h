@@ -81,6 +81,9 @@ const char* romp_last_error(void);
                                    conv (3x3 s1 32->32 + BN + residual + ReLU; res_buf = the block input x, out_buf = y), the op
                                    right before it -- kind ROMP_OP_NOP, every other field intact -- the FIRST (3x3 s1 32->32 + BN +
                                    ReLU on x).  H2 tensors, f16x2 weights, H and W multiples of 16.  plan.py fuses the pairs.    */
+#define ROMP_OP_BBLOCK64  14    /* the same for a 64-channel BasicBlock (csrc/conv_h2c.hip): both ops carry, in weight_aux, their
+                                   f16x2 weights repacked per wave for 16-channel MFMA rows (plan.pack_h2_wave16); H a multiple of
+                                   8, W of 16                                                                                   */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 typedef struct romp_op {

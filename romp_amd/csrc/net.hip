@@ -176,6 +176,13 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(x && y && n->ops[idx - 1].in_buf == op.res_buf, "bblock32: bad buffers %d -> %d", op.res_buf, op.out_buf);
             return launch_bblock32(n->ops[idx - 1], op, x, y, B, queue, st);
         }
+        case ROMP_OP_BBLOCK64: {
+            ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP, "bblock64: the op before it must be the NOP holding the first conv");
+            const float* x = resolve_in(n, op.res_buf, image);
+            float* y = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(x && y && n->ops[idx - 1].in_buf == op.res_buf, "bblock64: bad buffers %d -> %d", op.res_buf, op.out_buf);
+            return launch_bblock64(n->ops[idx - 1], op, x, y, B, queue, st);
+        }
         case ROMP_OP_NOP:
         case ROMP_OP_FORK:
         case ROMP_OP_JOIN:
@@ -274,12 +281,19 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
     { const int rc = conv_init(); if (rc) return rc; }
-    for (int i = 0; i < n_ops; ++i)
-        if (ops_host[i].kind == ROMP_OP_BBLOCK32) {            // its one-time set-up (hipMalloc / attributes) must not run inside a stream capture
-            const int rc = launch_bblock32(ops_host[i], ops_host[i], nullptr, nullptr, 0, nullptr, nullptr);
+    for (int i = 0, seen = 0; i < n_ops && seen != 3; ++i) {  // the fused blocks' one-time set-up (hipMalloc / attributes) must not run inside a stream capture
+        const int kind = ops_host[i].kind;
+        if (kind == ROMP_OP_BBLOCK32 && !(seen & 1) && i > 0) {
+            const int rc = launch_bblock32(ops_host[i - 1], ops_host[i], nullptr, nullptr, 0, nullptr, nullptr);
             if (rc) return rc;
-            break;
+            seen |= 1;
         }
+        if (kind == ROMP_OP_BBLOCK64 && !(seen & 2) && i > 0) {
+            const int rc = launch_bblock64(ops_host[i - 1], ops_host[i], nullptr, nullptr, 0, nullptr, nullptr);
+            if (rc) return rc;
+            seen |= 2;
+        }
+    }
     romp_net* n = new romp_net();
     n->ops.assign(ops_host, ops_host + n_ops);
     n->buf_floats.assign(buf_floats, buf_floats + n_bufs);
@@ -655,6 +669,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_MAXPOOL) { snprintf(out, n, "maxpool3s2"); return ROMP_OK; }
     if (op->kind == ROMP_OP_NOP) { snprintf(out, n, "nop"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK32) { snprintf(out, n, "bblock32"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_BBLOCK64) { snprintf(out, n, "bblock64"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BEV_PACK) { snprintf(out, n, "bev_pack"); return ROMP_OK; }

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OP_NOP, OP_BBLOCK32, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OP_NOP, OP_BBLOCK32, OP_BBLOCK64, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -266,6 +266,16 @@ def assign_formats(P):
                 op.term_fmt[role[1]] = fmt
 
 
+def pack_h2_wave16(t):
+    """The f16x2 weight pack of a 64 -> 64 3x3 conv ([tap 9][cin/16 4][piece 2][k-half 2][cout 64][8] int16, pack_conv_weight_h2)
+    re-ordered for csrc/conv_h2c.hip: wave w owns output channels 16 w .. 16 w + 15 and reads, per tap, 32-input-channel chunk kc
+    and piece, ONE 16-byte unit per lane -- the A operand of v_mfma_f32_16x16x32_f16: lane = 16 * kq + oc holds input channels
+    32 kc + 8 kq .. + 7 of output channel 16 w + oc.  -> [wave 4][tap 9][kc 2][piece 2][lane 64][8] (a pure permutation)."""
+    assert tuple(t.shape) == (9, 4, 2, 2, 64, 8), tuple(t.shape)
+    v = t.reshape(9, 2, 2, 2, 2, 4, 16, 8)                      # tap, kc, kq / 2, piece, kq % 2, wave, oc, 8
+    return v.permute(5, 0, 1, 3, 2, 4, 6, 7).contiguous().reshape(4, 9, 2, 2, 64, 8)
+
+
 def fuse_basic_blocks(P):
     """Peephole over the lowered program (after assign_formats): a 32-channel BasicBlock -- conv 3x3 s1 32->32 + BN + ReLU followed
     by conv 3x3 s1 32->32 + BN + (block input) + ReLU, model.py:54-83 -- whose tensors are all H2 becomes ONE launch
@@ -278,6 +288,7 @@ def fuse_basic_blocks(P):
     P.fused_blocks = 0
     if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_BLOCKS', '1') == '0':
         return 0
+    fuse_c = {'1': (32, 64), '32': (32,), '64': (64,)}.get(os.environ.get('ROMP_FUSE_BLOCKS', '1'), (32, 64))
     readers = {}
     for i, op in enumerate(P.ops):
         for b in [op.in_buf, op.res_buf] + [op.term_buf[k] for k in range(op.n_terms if op.kind == OP_FUSESUM else 0)]:
@@ -287,9 +298,10 @@ def fuse_basic_blocks(P):
         a, b = P.ops[i], P.ops[i + 1]
         if not (a.kind == OP_CONV and b.kind == OP_CONV):
             continue
-        plain = all(o.ksize == 3 and o.stride == 1 and o.groups == 1 and o.Cin == 32 and o.Cout == 32 and o.cin_pad == 32 and
-                    o.cout_pad == 32 and o.relu and o.weight_h2 and o.scale_h2 and o.pad_h == -1 and o.pad_w == -1 and
-                    o.out_rstride == 0 and o.out_bstride == 0 and o.H % 16 == 0 and o.W % 16 == 0 for o in (a, b))
+        C_ = a.Cin
+        plain = C_ in fuse_c and all(o.ksize == 3 and o.stride == 1 and o.groups == 1 and o.Cin == C_ and o.Cout == C_ and o.cin_pad == C_ and
+                    o.cout_pad == C_ and o.relu and o.weight_h2 and o.scale_h2 and o.pad_h == -1 and o.pad_w == -1 and
+                    o.out_rstride == 0 and o.out_bstride == 0 and o.H % (16 if C_ == 32 else 8) == 0 and o.W % 16 == 0 for o in (a, b))
         chained = (a.res_buf < 0 and b.in_buf == a.out_buf and a.out_buf >= 0 and b.res_buf == a.in_buf and a.in_buf >= 0 and b.out_buf >= 0 and
                    (b.res_cstride, b.res_coff) == (a.in_cstride, a.in_coff) and (b.in_cstride, b.in_coff) == (a.out_cstride, a.out_coff) and
                    a.stream == b.stream and (a.H, a.W) == (b.H, b.W))
@@ -299,10 +311,16 @@ def fuse_basic_blocks(P):
         writers_between = [j for j in range(i + 2, later[0] + 1) if P.ops[j].out_buf == a.out_buf] if later else [0]
         private = not later or bool(writers_between)
         if plain and chained and h2 and private and a.act_shift == b.act_shift:
-            a.kind, b.kind = OP_NOP, OP_BBLOCK32
+            if C_ == 64:                                      # the 64-channel kernel reads its weights per wave (16 output channels each)
+                by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
+                for o in (a, b):
+                    t = pack_h2_wave16(by_ptr[o.weight_h2].view(9, 4, 2, 2, 64, 8))
+                    P.consts.append(t)
+                    o.weight_aux = t.data_ptr()
+            a.kind, b.kind = OP_NOP, (OP_BBLOCK32 if C_ == 32 else OP_BBLOCK64)
             P.flops[i + 1] += P.flops[i]
             P.flops[i] = 0.0
-            P.bytes[i + 1] = 4.0 * a.H * a.W * 32 * 2
+            P.bytes[i + 1] = 4.0 * a.H * a.W * C_ * 2
             P.bytes[i] = 0.0
             P.fused_blocks += 1
     return P.fused_blocks

@@ -15,11 +15,13 @@ import re
 import sys
 from collections import defaultdict
 
-NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|stem_conv_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
+NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblock64_kernel|stem_conv_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
 FIRST = ('stem_conv_kernel', 'stem7_conv_kernel')
 
 
 def kernel_of(variant_name):
+    if variant_name in ('bblock32', 'bblock64'):
+        return variant_name + '_kernel'
     m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
@@ -47,7 +49,7 @@ def per_op(csv_path, counter, names):
             merged[-1][2] += v
         else:
             merged.append([d, k, v])
-    launching = [i for i, n in enumerate(names) if n not in ('fork', 'join')]
+    launching = [i for i, n in enumerate(names) if n not in ('fork', 'join', 'nop')]   # (nop: the first conv of a fused block)
     acc, cnt, forwards, pos, cur, skipped = defaultdict(float), defaultdict(int), 0, None, {}, []
     for d, k, v in merged:
         m = NET_KERNEL.search(k)
