@@ -281,14 +281,18 @@ def fuse_basic_blocks(P):
     by conv 3x3 s1 32->32 + BN + (block input) + ReLU, model.py:54-83 -- whose tensors are all H2 becomes ONE launch
     (csrc/conv_h2b.hip: the intermediate tile stays in LDS): the first conv's op turns into ROMP_OP_NOP (fields intact: the
     kernel takes its weights from there), the second into ROMP_OP_BBLOCK32.  Op indices, names and the flop / byte lists keep
-    their length; the pair's algorithmic bytes become x in + y out.  Single-image plans too (64 tiles there, a quarter of the
-    CUs, but 32 fewer launches on a launch-bound chain: network 2.15 -> 1.95 ms at B = 1); env ROMP_FUSE_BLOCKS=0 switches it
-    off (A/B runs).  -> number of fused blocks."""
+    their length; the pair's algorithmic bytes become x in + y out.  The same for 64-channel blocks (csrc/conv_h2c.hip,
+    ROMP_OP_BBLOCK64; their weights are repacked per wave into weight_aux).  Single-image plans fuse the 32-channel blocks only
+    (64 tiles there, a quarter of the CUs, but 32 fewer launches on a launch-bound chain: network 2.15 -> 1.95 ms at B = 1; the
+    64-channel kernel would run 32 tiles: 2.25 -> 2.45 ms per frame).  Env ROMP_FUSE_BLOCKS: 0 off, 32 / 64 one class, all
+    both everywhere (A/B runs).  -> number of fused blocks."""
     import os
     P.fused_blocks = 0
     if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_BLOCKS', '1') == '0':
         return 0
-    fuse_c = {'1': (32, 64), '32': (32,), '64': (64,)}.get(os.environ.get('ROMP_FUSE_BLOCKS', '1'), (32, 64))
+    fuse_c = {'1': (32, 64), '32': (32,), '64': (64,), 'all': (32, 64)}.get(os.environ.get('ROMP_FUSE_BLOCKS', '1'), (32, 64))
+    if getattr(P, 'split_k_items', 0) and os.environ.get('ROMP_FUSE_BLOCKS', '1') == '1':
+        fuse_c = (32,)                                         # a single image is 32 tiles of the 64-channel kernel: slower than its two convs
     readers = {}
     for i, op in enumerate(P.ops):
         for b in [op.in_buf, op.res_buf] + [op.term_buf[k] for k in range(op.n_terms if op.kind == OP_FUSESUM else 0)]:

@@ -1,5 +1,5 @@
 """Time the fused 32-channel BasicBlock kernel (csrc/conv_h2b.hip) against the same block as two conv launches.
-usage: [BB_B=32] [BB_H=128] python scripts/bblock_bench.py      (GPU; ROMP_FUSE_BLOCKS=0 gives the unfused lowering)"""
+usage: [BB_C=32|64] [BB_B=32] [BB_H=128|64] python scripts/bblock_bench.py      (GPU; ROMP_FUSE_BLOCKS=0 gives the unfused lowering)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,15 +8,15 @@ from romp_amd import lib as L
 from romp_amd.plan import Program, Act, set_conv_math
 
 
-def build(dev, H, fuse):
-    os.environ['ROMP_FUSE_BLOCKS'] = '1' if fuse else '0'
+def build(dev, H, fuse, Cc=32):
+    os.environ['ROMP_FUSE_BLOCKS'] = 'all' if fuse else '0'
     g = torch.Generator().manual_seed(0)
-    ws = [torch.randn(32, 32, 3, 3, generator=g) / (32 * 9) ** 0.5 for _ in range(3)]
-    sc = [torch.rand(32, generator=g) + 0.5 for _ in range(3)]
-    sh = [torch.randn(32, generator=g) * 0.2 for _ in range(3)]
+    ws = [torch.randn(Cc, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5 for _ in range(3)]
+    sc = [torch.rand(Cc, generator=g) + 0.5 for _ in range(3)]
+    sh = [torch.randn(Cc, generator=g) * 0.2 for _ in range(3)]
     P = Program(dev)
     set_conv_math(P, 'f16x2')
-    a0 = P.conv('c0', Act(L.BUF_IMAGE, 32, H, H, 32), [ws[0]], [sc[0]], [sh[0]], 3, 1, True)
+    a0 = P.conv('c0', Act(L.BUF_IMAGE, Cc, H, H, Cc), [ws[0]], [sc[0]], [sh[0]], 3, 1, True)
     a1 = P.conv('c1', a0, [ws[1]], [sc[1]], [sh[1]], 3, 1, True)
     a2 = P.conv('c2', a1, [ws[2]], [sc[2]], [sh[2]], 3, 1, True, res=a0)
     ops = P.op_array()
@@ -53,14 +53,15 @@ def trace_report(lib):
 
 
 if __name__ == '__main__':
-    B, H = int(os.environ.get('BB_B', '32')), int(os.environ.get('BB_H', '128'))
+    Cc = int(os.environ.get('BB_C', '32'))
+    B, H = int(os.environ.get('BB_B', '32')), int(os.environ.get('BB_H', '128' if Cc == 32 else '64'))
     dev = torch.device('cuda:0')
     lib = L.load()
-    x = torch.randn(B, H, H, 32, device=dev)
+    x = torch.randn(B, H, H, Cc, device=dev)
     dummy = torch.empty(16, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for fuse in ((1,) if os.environ.get('BB_FUSED_ONLY') == '1' else (1, 0, 1, 0)):
-        P, ops = build(dev, H, fuse)
+        P, ops = build(dev, H, fuse, Cc)
         h = C.c_void_p()
         sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
         L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))

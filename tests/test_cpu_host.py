@@ -291,7 +291,7 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM:
             written[op.out_buf] = op.out_fmt
-        elif op.kind == L.OP_BBLOCK32:                       # fused BasicBlock: reads x (its residual buffer), writes y, both H2
+        elif op.kind in (L.OP_BBLOCK32, L.OP_BBLOCK64):      # fused BasicBlock: reads x (its residual buffer), writes y, both H2
             assert written.get(op.res_buf) == L.FMT_H2 and op.res_fmt == L.FMT_H2 and op.out_fmt == L.FMT_H2, name
             n_h2 += 1
             written[op.out_buf] = op.out_fmt
@@ -396,3 +396,16 @@ def test_export_cli_bev_host_tables(tmp_path):
     assert np.allclose(anchors, cam3dmap_anchor(60, 128))
     dev_ops = [o for o in plan['ops'] if o.weight and not (o.weight & export.HOST_BIT)]
     assert len(dev_ops) > 300
+
+
+def test_pack_h2_wave16_is_the_documented_permutation():
+    """plan.pack_h2_wave16 (weights of the 64-channel fused block, csrc/conv_h2c.hip): lane 16 kq + oc of wave w holds input
+    channels 32 kc + 8 kq .. + 7 of output channel 16 w + oc, for every tap and piece."""
+    from romp_amd.plan import pack_h2_wave16
+    t = torch.arange(9 * 4 * 2 * 2 * 64 * 8, dtype=torch.int32).reshape(9, 4, 2, 2, 64, 8)
+    n = pack_h2_wave16(t)
+    assert tuple(n.shape) == (4, 9, 2, 2, 64, 8)
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        w, tap, kc, pc, kq, oc, e = (rs.randint(k) for k in (4, 9, 2, 2, 4, 16, 8))
+        assert n[w, tap, kc, pc, 16 * kq + oc, e] == t[tap, 2 * kc + kq // 2, pc, kq % 2, 16 * w + oc, e]

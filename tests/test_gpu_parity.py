@@ -336,20 +336,21 @@ def test_net_range_calibration(dev):
     assert bool(torch.isfinite(cm2).all()) and bool(torch.isfinite(pm2).all()), 'saturation, not inf / NaN'
 
 
-@pytest.mark.parametrize('B,H', [(1, 32), (3, 64), (2, 48)])
-def test_fused_basic_block32(dev, B, H):
-    """csrc/conv_h2b.hip: a 32-channel BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
+@pytest.mark.parametrize('B,H,Cc', [(1, 32, 32), (3, 64, 32), (2, 48, 32), (1, 16, 64), (3, 64, 64), (2, 48, 64)])
+def test_fused_basic_block(dev, B, H, Cc, monkeypatch):
+    """csrc/conv_h2b.hip / conv_h2c.hip: a 32- / 64-channel BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
     ordinary conv producing the H2 block input, then the block -- lowered by plan.py (which must fuse the pair), run through
     romp_net_create / romp_net_forward, against torch on the CPU: image borders (the intermediate's zero padding), interior
     tiles, odd tile counts, batch > 1.  Same bound as the single layers, two layers deeper: 5e-5 of the output's magnitude."""
     import ctypes as C
     from romp_amd import lib as L
     from romp_amd.plan import Program, Act, set_conv_math, decode_h2
-    g = torch.Generator().manual_seed(100 * B + H)
-    x = torch.randn(B, H, H, 32, generator=g)
-    ws = [torch.randn(32, 32, 3, 3, generator=g) / (32 * 9) ** 0.5 for _ in range(3)]
-    sc = [torch.rand(32, generator=g) + 0.5 for _ in range(3)]
-    sh = [torch.randn(32, generator=g) * 0.2 for _ in range(3)]
+    monkeypatch.setenv('ROMP_FUSE_BLOCKS', 'all')
+    g = torch.Generator().manual_seed(100 * B + H + Cc)
+    x = torch.randn(B, H, H, Cc, generator=g)
+    ws = [torch.randn(Cc, Cc, 3, 3, generator=g) / (Cc * 9) ** 0.5 for _ in range(3)]
+    sc = [torch.rand(Cc, generator=g) + 0.5 for _ in range(3)]
+    sh = [torch.randn(Cc, generator=g) * 0.2 for _ in range(3)]
 
     def cbr(t, i, res=None):
         y = F.conv2d(t, ws[i], None, padding=1) * sc[i].view(1, -1, 1, 1) + sh[i].view(1, -1, 1, 1)
@@ -358,11 +359,12 @@ def test_fused_basic_block32(dev, B, H):
     ref = cbr(cbr(t0, 1), 2, res=t0).permute(0, 2, 3, 1)
     P = Program(dev)
     set_conv_math(P, 'f16x2')
-    a0 = P.conv('c0', Act(L.BUF_IMAGE, 32, H, H, 32), [ws[0]], [sc[0]], [sh[0]], 3, 1, True)
+    a0 = P.conv('c0', Act(L.BUF_IMAGE, Cc, H, H, Cc), [ws[0]], [sc[0]], [sh[0]], 3, 1, True)
     a1 = P.conv('c1', a0, [ws[1]], [sc[1]], [sh[1]], 3, 1, True)
     a2 = P.conv('c2', a1, [ws[2]], [sc[2]], [sh[2]], 3, 1, True, res=a0)
     ops = P.op_array()
-    assert P.fused_blocks == 1 and [o.kind for o in P.ops] == [L.OP_CONV, L.OP_NOP, L.OP_BBLOCK32], [o.kind for o in P.ops]
+    fused_kind = L.OP_BBLOCK32 if Cc == 32 else L.OP_BBLOCK64
+    assert P.fused_blocks == 1 and [o.kind for o in P.ops] == [L.OP_CONV, L.OP_NOP, fused_kind], [o.kind for o in P.ops]
     assert P.ops[2].out_fmt == L.FMT_H2
     lib = L.load()
     h = C.c_void_p()
@@ -377,9 +379,9 @@ def test_fused_basic_block32(dev, B, H):
             L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
             L.check(lib.romp_net_read_buffer(h, a2.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
             torch.cuda.synchronize()
-            y = decode_h2(out.cpu().reshape(B, H, H, 32))
+            y = decode_h2(out.cpu().reshape(B, H, H, Cc))
             err = (y - ref).abs().max().item() / ref.abs().max().item()
-            print(f'fused BasicBlock B={B} {H}x{H} run {rep}: relative err {err:.3e}')
+            print(f'fused BasicBlock B={B} {H}x{H}x{Cc} run {rep}: relative err {err:.3e}')
             assert err < 5e-5, err
     finally:
         lib.romp_net_destroy(h)
