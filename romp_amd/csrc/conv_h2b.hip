@@ -78,17 +78,6 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
         const float* src = tid < 32 ? p.scale : tid < 64 ? p.w : tid < 96 ? p.scale_h : p.shift;
         sS[tid] = src[tid & 31] * p.act_scale;
     }
-    // ---- the weights of both convs, all taps and both chunks, resident: lane (li, lh) = channel li, k-half lh
-    frag w1[2][9][2], w2[2][9][2];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {                    // packed [tap][chunk 2][piece 2][k-half 2][32] units
-                w1[ch][tap][pc] = __builtin_bit_cast(frag, p.w3[(((tap * 2 + ch) * 2 + pc) * 2 + lh) * 32 + li]);
-                w2[ch][tap][pc] = __builtin_bit_cast(frag, p.wh[(((tap * 2 + ch) * 2 + pc) * 2 + lh) * 32 + li]);
-            }
     auto tile_of = [&](int k) __attribute__((always_inline)) { return decode_item(p, q, j0 + k * nwg_q, 32); };
 
     // DMA pieces of this wave for one 16-channel input stage (25 pieces of 64 units cover the 20 x 80 units exactly: piece 4 k + wv
@@ -175,6 +164,17 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
         for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, ch, kk);
+    // ---- the weights of both convs, all taps and both chunks, resident (asked for AFTER the first halo: both trips overlap): lane (li, lh) = channel li, k-half lh
+    frag w1[2][9][2], w2[2][9][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {                    // packed [tap][chunk 2][piece 2][k-half 2][32] units
+                w1[ch][tap][pc] = __builtin_bit_cast(frag, p.w3[(((tap * 2 + ch) * 2 + pc) * 2 + lh) * 32 + li]);
+                w2[ch][tap][pc] = __builtin_bit_cast(frag, p.wh[(((tap * 2 + ch) * 2 + pc) * 2 + lh) * 32 + li]);
+            }
     // A "use" of every weight register in front of the tile loop: hipcc then waits for these loads HERE, once (left to the first
     // MFMA inside the loop its wait is a conservative vmcnt(0) on every iteration)
 #pragma unroll

@@ -69,17 +69,6 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
     const int n_mine = (p.per_queue - j0 + nwg_q - 1) / nwg_q;
     auto tile_of = [&](int k) __attribute__((always_inline)) { return decode_item(p, qx, j0 + k * nwg_q, 32); };
 
-    // ---- this wave's weights: 16 output channels x 64 input channels x 9 taps x 2 pieces of each conv
-    frag w1[9][2][2], w2[9][2][2];                             // [tap][k-chunk of 32 input channels][piece]
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                w1[tap][kc][pc] = __builtin_bit_cast(frag, p.w3[(((wv * 9 + tap) * 2 + kc) * 2 + pc) * 64 + lane]);
-                w2[tap][kc][pc] = __builtin_bit_cast(frag, p.wh[(((wv * 9 + tap) * 2 + kc) * 2 + pc) * 64 + lane]);
-            }
     // scale / shift of this lane's 4 channels (16 wv + 4 q ..), PRE-MULTIPLIED by 2^act_shift: m and y are produced in the scaled
     // domain the H2 pieces live in (ReLU commutes with the positive factor; the residual's pieces are x * 2^act_shift already)
     f32x4c s1, b1, s2, b2;
@@ -148,6 +137,17 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
     Item it = tile_of(0);
 #pragma unroll
     for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, kk);
+    // ---- this wave's weights (asked for AFTER the first halo: both trips overlap): 16 output channels x 64 input channels x 9 taps x 2 pieces of each conv
+    frag w1[9][2][2], w2[9][2][2];                             // [tap][k-chunk of 32 input channels][piece]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                w1[tap][kc][pc] = __builtin_bit_cast(frag, p.w3[(((wv * 9 + tap) * 2 + kc) * 2 + pc) * 64 + lane]);
+                w2[tap][kc][pc] = __builtin_bit_cast(frag, p.wh[(((wv * 9 + tap) * 2 + kc) * 2 + pc) * 64 + lane]);
+            }
     // a "use" of every weight register in front of the tile loop: hipcc waits for these loads HERE, once; the halo DMAs (invisible to
     // it) are covered by the explicit wait.  conv1's weights are pinned to AGPRs (MFMA reads them there), conv2's stay in VGPRs.
 #pragma unroll
@@ -259,18 +259,18 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
             // (a) the two edge blocks: no row reuse (54 MFMAs each).  Under them: the previous tile's last output row, then this
             // tile's residual parking
             // fragment reads run PF units (a unit = the MFMAs fed by one fragment pair) ahead of their MFMAs: unit u < 36 is edge block
-            // u / 18, tap (u % 18) / 2, k-chunk u % 2; unit 36 + ((R * 3 + dx) * 2 + kc) the row-block fragment of input row R
-            constexpr int PF = 3, NU = 36 + X::IR * 6;
-            frag xf[PF + 1][2];
+            // u % 2, tap u / 4, k-chunk (u / 2) % 2; unit 36 + ((R * 3 + dx) * 2 + kc) the row-block fragment of input row R
+            constexpr int PF = 3, NU = 36 + X::IR * 6, RING = PF + 2;   // (+ 2: the edge blocks consume two units at a time)
+            frag xf[RING][2];
             auto read_x = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
                 for (int pc = 0; pc < 2; ++pc) {
                     if (u < 36) {
-                        const int eb = u / 18, tap = (u % 18) / 2, kc = u % 2;
-                        xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + (eb ? xe1 : xe0) + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
+                        const int eb = u % 2, tap = u / 4, kc = (u / 2) % 2;
+                        xf[u % RING][pc] = *reinterpret_cast<const frag*>(sBuf + (eb ? xe1 : xe0) + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
                     } else {
                         const int v = u - 36, R = v / 6, dx = (v % 6) / 2, kc = v % 2;
-                        xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + xa + ((8 * kc + pc) * X::XPL + R * X::IC + dx) * 16);
+                        xf[u % RING][pc] = *reinterpret_cast<const frag*>(sBuf + xa + ((8 * kc + pc) * X::XPL + R * X::IC + dx) * 16);
                     }
                 }
             };
@@ -278,26 +278,27 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
             for (int u = 0; u < PF; ++u) read_x(u);
             constexpr int GE = 108, NE = FIN_N + PARK_N;
 #pragma unroll
-            for (int eb = 0; eb < 2; ++eb)
+            for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap)
+                for (int kc = 0; kc < 2; ++kc) {
+                    const int u = (tap * 2 + kc) * 2;          // units u (block E0) and u + 1 (E1): their MFMAs take turns (no two in a row on one accumulator)
+                    if (u + PF < NU) read_x(u + PF);
+                    if (u + 1 + PF < NU) read_x(u + 1 + PF);
 #pragma unroll
-                    for (int kc = 0; kc < 2; ++kc) {
-                        const int u = (eb * 9 + tap) * 2 + kc;
-                        if (u + PF < NU) read_x(u + PF);
-                        const frag (&x)[2] = xf[u % (PF + 1)];
+                    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                        for (int pr = 0; pr < 3; ++pr) {
+                        for (int eb = 0; eb < 2; ++eb) {
+                            const frag (&x)[2] = xf[(u + eb) % RING];
                             if (!(DBG & 8))
                                 accE[eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], accE[eb], 0, 0, 0);
-                            const int g = ((eb * 9 + tap) * 2 + kc) * 3 + pr;
+                            const int g = ((tap * 2 + kc) * 3 + pr) * 2 + eb;
                             int lo, hi;
                             share(g, GE, NE, lo, hi);
 #pragma unroll
                             for (int t = lo; t < hi; ++t) { if (t < FIN_N) fin_micro(itp, k > 0, X::TH - 1, t); else park_micro(t - FIN_N); }
                             SIDE_PIN();
                         }
-                    }
+                }
             // (b) the ten row blocks, input row after input row.  Under input row R: the hand-over of the edge blocks (R = 0, 1), then of
             // m row R - 3 (complete since input row R - 1)
 #pragma unroll
@@ -311,15 +312,15 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
                     for (int kc = 0; kc < 2; ++kc) {
                         const int u = 36 + (R * 3 + dx) * 2 + kc;
                         if (u + PF < NU) read_x(u + PF);
-                        const frag (&x)[2] = xf[u % (PF + 1)];
+                        const frag (&x)[2] = xf[u % RING];
 #pragma unroll
-                        for (int dy = dy_lo; dy <= dy_hi; ++dy)
+                        for (int pr = 0; pr < 3; ++pr)          // (products outside, rows inside: consecutive MFMAs on different accumulators)
 #pragma unroll
-                            for (int pr = 0; pr < 3; ++pr) {
+                            for (int dy = dy_lo; dy <= dy_hi; ++dy) {
                                 const int tap = dy * 3 + dx;
                                 if (!(DBG & 8))
                                     acc1[R - dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], acc1[R - dy], 0, 0, 0);
-                                const int g = (((dx * 2 + kc) * nv) + (dy - dy_lo)) * 3 + pr;
+                                const int g = (((dx * 2 + kc) * 3) + pr) * nv + (dy - dy_lo);
                                 int lo, hi;
                                 share(g, G, HAND_N, lo, hi);
 #pragma unroll
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
                                         hand_micro(accE[R], in, R == 0 || e1_act, hse0 + (R ? 8 * X::MC * 16 : 0), t);
                                     } else if (R >= 3) {
                                         const int r = R - 3;
-                                        hand_micro(acc1[r], (unsigned)(iy_m0 + r) < (unsigned)p.Ho, true, hs + r * X::MC * 16, t);
+                                        // (m rows 1..8 are output rows -1..8 of the tile + 1: always inside the image; row 0 may lie above it)
+                                        hand_micro(acc1[r], r == 0 ? iy_m0 >= 0 : true, true, hs + r * X::MC * 16, t);
                                     }
                                 }
                                 SIDE_PIN();
@@ -338,7 +340,11 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
                     }
             }
             ROMP_TRACE(11);
-            if (DBG & 2) asm volatile("" :: "v"(acc1[0]), "v"(acc1[3]), "v"(acc1[6]), "v"(acc1[9]), "v"(accE[0]), "v"(accE[1]));
+            if (DBG & 2) {                                     // (knock-out builds: keep every MFMA)
+#pragma unroll
+                for (int r = 0; r < X::MR; ++r) asm volatile("" :: "v"(acc1[r]));
+                asm volatile("" :: "v"(accE[0]), "v"(accE[1]));
+            }
 #pragma unroll
             for (int t = 0; t < HAND_N; ++t) hand_micro(acc1[X::MR - 1], (unsigned)(iy_m0 + X::MR - 1) < (unsigned)p.Ho, true, hs + (X::MR - 1) * X::MC * 16, t);
             ROMP_TRACE(13);
@@ -380,13 +386,13 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
                     if (u + PF2 < NU2) read_m(u + PF2);
                     const frag (&x)[2] = xg[u % (PF2 + 1)];
 #pragma unroll
-                    for (int dy = dy_lo; dy <= dy_hi; ++dy)
+                    for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-                        for (int pr = 0; pr < 3; ++pr) {
+                        for (int dy = dy_lo; dy <= dy_hi; ++dy) {
                             const int tap = dy * 3 + dx;
                             if (!(DBG & 8))
                                 acc2[R - dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], acc2[R - dy], 0, 0, 0);
-                            const int g = (((dx * 2 + kc) * nv) + (dy - dy_lo)) * 3 + pr;
+                            const int g = (((dx * 2 + kc) * 3) + pr) * nv + (dy - dy_lo);
                             int lo, hi;
                             share(g, G, NS, lo, hi);
 #pragma unroll
@@ -400,7 +406,10 @@ __global__ __launch_bounds__(256, 1) void bblock64_kernel(ConvParams p) {
                 }
         }
         ROMP_TRACE(17);
-        if (DBG & 4) asm volatile("" :: "v"(acc2[0]), "v"(acc2[2]), "v"(acc2[4]), "v"(acc2[6]), "v"(acc2[7]));
+        if (DBG & 4) {
+#pragma unroll
+            for (int r = 0; r < X::TH; ++r) asm volatile("" :: "v"(acc2[r]));
+        }
         // ---- 4. the next halo has landed, for every wave; m may be overwritten
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
