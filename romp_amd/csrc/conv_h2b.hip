@@ -472,6 +472,11 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
 
 // `op` is the block's SECOND conv (its residual is the block input x, its output y); `op1` the first (weights / scale / shift).
 int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
+    {   // two implementations: this file's (v1: 16x16 tiles, one wave per SIMD) and conv_h2c.hip's row-pipelined one (two waves per SIMD)
+        static int use_r = -1;
+        if (use_r < 0) { const char* e = getenv("ROMP_BBLOCK32"); use_r = (e && !strcmp(e, "v1")) ? 0 : 1; }   // default: the row-pipelined kernel
+        if (use_r && op1.weight_aux && op.weight_aux && op.H % 8 == 0) return launch_bblock32r(op1, op, x, y, B, queue, st);
+    }
     ROMP_REQUIRE(op.ksize == 3 && op.stride == 1 && op.Cin == 32 && op.Cout == 32 && op.cin_pad == 32 && op.cout_pad == 32 && op.groups == 1 &&
                  op1.ksize == 3 && op1.stride == 1 && op1.Cin == 32 && op1.Cout == 32 && op1.cin_pad == 32 && op1.cout_pad == 32 && op1.groups == 1,
                  "bblock32: two 3x3 stride-1 32 -> 32 convs expected");

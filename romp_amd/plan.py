@@ -267,13 +267,15 @@ def assign_formats(P):
 
 
 def pack_h2_wave16(t):
-    """The f16x2 weight pack of a 64 -> 64 3x3 conv ([tap 9][cin/16 4][piece 2][k-half 2][cout 64][8] int16, pack_conv_weight_h2)
-    re-ordered for csrc/conv_h2c.hip: wave w owns output channels 16 w .. 16 w + 15 and reads, per tap, 32-input-channel chunk kc
-    and piece, ONE 16-byte unit per lane -- the A operand of v_mfma_f32_16x16x32_f16: lane = 16 * kq + oc holds input channels
-    32 kc + 8 kq .. + 7 of output channel 16 w + oc.  -> [wave 4][tap 9][kc 2][piece 2][lane 64][8] (a pure permutation)."""
-    assert tuple(t.shape) == (9, 4, 2, 2, 64, 8), tuple(t.shape)
-    v = t.reshape(9, 2, 2, 2, 2, 4, 16, 8)                      # tap, kc, kq / 2, piece, kq % 2, wave, oc, 8
-    return v.permute(5, 0, 1, 3, 2, 4, 6, 7).contiguous().reshape(4, 9, 2, 2, 64, 8)
+    """The f16x2 weight pack of a C -> C 3x3 conv (C = 32, 64: [tap 9][C/16][piece 2][k-half 2][cout C][8] int16,
+    pack_conv_weight_h2) re-ordered for csrc/conv_h2c.hip: a wave of channel group cg owns output channels 16 cg .. 16 cg + 15 and
+    reads, per tap, 32-input-channel chunk kc and piece, ONE 16-byte unit per lane -- the A operand of v_mfma_f32_16x16x32_f16:
+    lane = 16 * kq + oc holds input channels 32 kc + 8 kq .. + 7 of output channel 16 cg + oc.
+    -> [group C/16][tap 9][kc C/32][piece 2][lane 64][8] (a pure permutation)."""
+    Cc = t.shape[4]
+    assert tuple(t.shape) == (9, Cc // 16, 2, 2, Cc, 8) and Cc in (32, 64), tuple(t.shape)
+    v = t.reshape(9, Cc // 32, 2, 2, 2, Cc // 16, 16, 8)        # tap, kc, kq / 2, piece, kq % 2, group, oc, 8
+    return v.permute(5, 0, 1, 3, 2, 4, 6, 7).contiguous().reshape(Cc // 16, 9, Cc // 32, 2, 64, 8)
 
 
 def fuse_basic_blocks(P):
@@ -315,10 +317,12 @@ def fuse_basic_blocks(P):
         writers_between = [j for j in range(i + 2, later[0] + 1) if P.ops[j].out_buf == a.out_buf] if later else [0]
         private = not later or bool(writers_between)
         if plain and chained and h2 and private and a.act_shift == b.act_shift:
-            if C_ == 64:                                      # the 64-channel kernel reads its weights per wave (16 output channels each)
+            # the row-pipelined kernels (conv_h2c.hip) read their weights per wave (16 output channels each).  32 channels: batch plans only
+            # (two workgroups per CU; a single image's tiles are better off on conv_h2b.hip's kernel: 2.10 vs 2.15 ms at B = 1)
+            if C_ == 64 or (os.environ.get('ROMP_BBLOCK32', 'r') == 'r' and not getattr(P, 'split_k_items', 0)):
                 by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
                 for o in (a, b):
-                    t = pack_h2_wave16(by_ptr[o.weight_h2].view(9, 4, 2, 2, 64, 8))
+                    t = pack_h2_wave16(by_ptr[o.weight_h2].view(9, C_ // 16, 2, 2, C_, 8))
                     P.consts.append(t)
                     o.weight_aux = t.data_ptr()
             a.kind, b.kind = OP_NOP, (OP_BBLOCK32 if C_ == 32 else OP_BBLOCK64)

@@ -404,7 +404,7 @@ def test_pack_h2_wave16_is_the_documented_permutation():
     from romp_amd.plan import pack_h2_wave16
     t = torch.arange(9 * 4 * 2 * 2 * 64 * 8, dtype=torch.int32).reshape(9, 4, 2, 2, 64, 8)
     n = pack_h2_wave16(t)
-    assert tuple(n.shape) == (4, 9, 2, 2, 64, 8)
+    assert tuple(n.shape) == (4, 9, 2, 2, 64, 8) and tuple(pack_h2_wave16(t[:, :2, :, :, :32]).shape) == (2, 9, 1, 2, 64, 8)
     rs = np.random.RandomState(0)
     for _ in range(200):
         w, tap, kc, pc, kq, oc, e = (rs.randint(k) for k in (4, 9, 2, 2, 4, 16, 8))
