@@ -399,7 +399,10 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
             const int dy_lo = Rl - (X::THW - 1) > 0 ? Rl - (X::THW - 1) : 0, dy_hi = Rl < 2 ? Rl : 2;        // output rows Rl - dy in [0, THW)
             const int nv = dy_hi - dy_lo + 1;
             const int G = 3 * X::NKC * nv * 3;
-            const int f_lo = Rl * X::NI / X::MRW2, f_hi = (Rl + 1) * X::NI / X::MRW2;     // this row's share of the DMA pieces
+            // this row's share of the DMA pieces: all of them under the first half of the rows (the last ones need time to land
+            // before the barrier at the end of the tile)
+            constexpr int FR = (X::MRW2 + 1) / 2;
+            const int f_lo = Rl < FR ? Rl * X::NI / FR : X::NI, f_hi = Rl < FR ? (Rl + 1) * X::NI / FR : X::NI;
             const int NS = (Rl >= 3 ? FIN_N : 0) + (f_hi - f_lo);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)

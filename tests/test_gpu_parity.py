@@ -336,9 +336,10 @@ def test_net_range_calibration(dev):
     assert bool(torch.isfinite(cm2).all()) and bool(torch.isfinite(pm2).all()), 'saturation, not inf / NaN'
 
 
-@pytest.mark.parametrize('B,H,Cc', [(1, 32, 32), (3, 64, 32), (2, 48, 32), (1, 16, 64), (3, 64, 64), (2, 48, 64)])
-def test_fused_basic_block(dev, B, H, Cc, monkeypatch):
-    """csrc/conv_h2b.hip / conv_h2c.hip: a 32- / 64-channel BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
+@pytest.mark.parametrize('B,H,Cc,impl', [(1, 32, 32, 'r'), (3, 64, 32, 'r'), (2, 48, 32, 'r'), (1, 32, 32, 'v1'), (3, 64, 32, 'v1'), (2, 48, 32, 'v1'),
+                                         (1, 16, 64, 'r'), (3, 64, 64, 'r'), (2, 48, 64, 'r')])
+def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
+    """csrc/conv_h2b.hip ('v1', 32 channels) / conv_h2c.hip ('r', 32 and 64 channels): a BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
     ordinary conv producing the H2 block input, then the block -- lowered by plan.py (which must fuse the pair), run through
     romp_net_create / romp_net_forward, against torch on the CPU: image borders (the intermediate's zero padding), interior
     tiles, odd tile counts, batch > 1.  Same bound as the single layers, two layers deeper: 5e-5 of the output's magnitude."""
@@ -366,6 +367,10 @@ def test_fused_basic_block(dev, B, H, Cc, monkeypatch):
     fused_kind = L.OP_BBLOCK32 if Cc == 32 else L.OP_BBLOCK64
     assert P.fused_blocks == 1 and [o.kind for o in P.ops] == [L.OP_CONV, L.OP_NOP, fused_kind], [o.kind for o in P.ops]
     assert P.ops[2].out_fmt == L.FMT_H2
+    if impl == 'v1':                                         # conv_h2b.hip's 16x16-tile kernel (single-image plans): no per-wave weight packs
+        ops[1].weight_aux = ops[2].weight_aux = None
+    else:                                                    # conv_h2c.hip's row-pipelined kernels
+        assert ops[1].weight_aux and ops[2].weight_aux
     lib = L.load()
     h = C.c_void_p()
     sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
