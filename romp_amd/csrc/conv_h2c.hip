@@ -1,14 +1,17 @@
-// conv_h2c.hip -- a whole 64-channel BasicBlock (simple_romp/romp/model.py:54-83) in ONE kernel on the f16x2 split:
-//     y = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x),   64 -> 64 -> 64 channels, stride 1, H2 tensors in and out.
-// The 64-channel @64^2 class is the network's largest after the 32-channel blocks were fused (66 launches, 2.75 ms of a 12.2 ms
-// forward at B = 32, 0.29 of the matrix roof as separate convs).  Same idea as conv_h2b.hip -- x read once (haloed), y written
-// once, the intermediate m never leaves the CU, both convs' weights register-resident -- with the geometry the larger weights
-// force:
-//   * one 256-thread workgroup per CU, ONE wave per SIMD (512 registers); wave w owns OUTPUT CHANNELS 16 w .. 16 w + 15 of both
-//     convs for every pixel of the tile: its share of the split weights is 2 x 144 registers (a wave that owned pixels instead
-//     would need all 2 x 576).  M = 16 channels means v_mfma_f32_16x16x32_f16: A = 16 channels x 32 input channels (weights,
-//     registers), B = 32 input channels x 16 pixels (an LDS fragment), D = 4 consecutive channels of one pixel per lane;
-//   * tiles of 8 x 16 output pixels: 12 x 20 input halo (60 KB in LDS), 10 x 18 halo of m (48 KB);
+// conv_h2c.hip -- a whole 64- or 32-channel BasicBlock (simple_romp/romp/model.py:54-83) in ONE kernel on the f16x2 split, in the
+// ROW-PIPELINED form:   y = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x),   C -> C -> C channels, stride 1, H2 tensors in and out.
+// Written for the 64-channel @64^2 class (the network's largest once conv_h2b.hip had fused the 32-channel blocks: 66 launches,
+// 2.75 ms of a 12.2 ms forward at B = 32, 0.29 of the matrix roof as separate convs), then instantiated for 32 channels too, where
+// it runs two workgroups per CU and replaced conv_h2b.hip's kernel in batch plans.  Same idea as there -- x read once (haloed),
+// y written once, the intermediate m never leaves the CU, both convs' weights register-resident -- with the geometry the larger
+// weights force:
+//   * a wave owns a CHANNEL GROUP of 16 output channels of both convs: its share of the split weights is 2 x 72 registers per 32
+//     input channels (C = 64: 288 per wave, one workgroup per CU, ONE wave per SIMD; a wave that owned pixels instead would
+//     need all 2 x 576.  C = 32: 144 per wave, two workgroups per CU).  M = 16 channels means v_mfma_f32_16x16x32_f16: A = 16
+//     channels x 32 input channels (weights, registers), B = 32 input channels x 16 pixels (an LDS fragment), D = 4 consecutive
+//     channels of one pixel per lane.  C = 64: four channel groups, every wave walks all rows of the tile; C = 32: two channel groups
+//     x two ROW GROUPS (m rows 0..4 / 5..9 in conv1, output rows 0..3 / 4..7 in conv2);
+//   * tiles of 8 x 16 output pixels: 12 x 20 input halo (C = 64: 60 KB in LDS), 10 x 18 halo of m (48 KB);
 //   * a pixel block is 16 pixels of ONE ROW, and input rows are walked top to bottom: the fragment of (input row R, column shift
 //     dx) feeds the output rows R, R - 1, R - 2 (dy = 0, 1, 2) -- 2 LDS reads per 9 MFMAs -- and a row of m (of y) is complete two
 //     input rows later, so its hand-over (finish) rides under the MFMAs of the following row: no block slots, no tail but the
@@ -19,9 +22,9 @@
 //   * scale / shift of a lane's 4 channels live in registers (no tables); the residual is parked per lane in LDS as in
 //     conv_h2b.hip; the next tile's halo arrives by raw-buffer LDS-DMA under conv2; the last output row of a tile is finished
 //     under the next tile's first MFMAs.
-// ConvParams as used here: in = x (H2), res = x, out = y (H2); w3 = conv1's weights REPACKED per wave ([wave 4][tap 9][k-chunk 2]
-// [piece 2][lane 64] 16-byte units, plan.pack_h2_wave16), wh = conv2's; scale / w = conv1's f16x2 scale and shift (64 floats
-// each), scale_h / shift = conv2's; the geometry fields as for a conv.
+// ConvParams as used here: in = x (H2), res = x, out = y (H2); w3 = conv1's weights REPACKED per channel group ([group C/16][tap 9]
+// [k-chunk C/32][piece 2][lane 64] 16-byte units, plan.pack_h2_wave16), wh = conv2's; scale / w = conv1's f16x2 scale and shift
+// (C floats each), scale_h / shift = conv2's; the geometry fields as for a conv.
 #include "conv_split.h"
 #include "conv_fuse.h"
 #include <string.h>
