@@ -15,13 +15,15 @@ import re
 import sys
 from collections import defaultdict
 
-NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblock64_kernel|stem_conv_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
+NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|stem_conv_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
 FIRST = ('stem_conv_kernel', 'stem7_conv_kernel')
 
 
 def kernel_of(variant_name):
-    if variant_name in ('bblock32', 'bblock64'):
-        return variant_name + '_kernel'
+    if variant_name == 'bblock32':                           # conv_h2b.hip's kernel (single-image plans) or the row-pipelined one
+        return ('bblock32_kernel', 'bblockr_kernel<32')
+    if variant_name == 'bblock64':
+        return ('bblockr_kernel<64',)
     m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
@@ -63,7 +65,7 @@ def per_op(csv_path, counter, names):
             cur = {}
         i = launching[pos]
         want = kernel_of(names[i])
-        if want is not None and want not in k:
+        if want is not None and not any(w in k for w in ((want,) if isinstance(want, str) else want)):
             # not a forward of the profiled table (the float32 calibration forward at start-up, an autotune launch): drop it
             skipped.append('dispatch %d is %s, op %d of the table is %s' % (d, k[:60], i, names[i]))
             pos = None
