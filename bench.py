@@ -131,8 +131,11 @@ def roofline_report(net, images, pmc_workload=None):
         roof.update(achieved=round(hbm_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(hbm_frac, 4))
     else:
         roof.update(achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(mfma_frac, 4))
+    fused = name.startswith('bblock')          # the fused BasicBlock ops run csrc/conv_h2c.hip's kernel in batch plans (16x16x32 MFMAs)
+    if fused:
+        roof['kernel_symbol'] = 'romp::bblockr_kernel<%s, 0>' % name[len('bblock'):] + (' (single-image plans: romp::bblock32_kernel<0>)' if name == 'bblock32' else '')
     roof.update(traffic=None,
-                pipe=('%s MFMA 32x32x16, %d piece products per f32 product' % ('bf16' if bx3 else 'f16', products)) if (bx3 or h2) else 'f32 MFMA 32x32x2',
+                pipe=('%s MFMA %s, %d piece products per f32 product' % ('bf16' if bx3 else 'f16', '16x16x32' if fused else '32x32x16', products)) if (bx3 or h2) else 'f32 MFMA 32x32x2',
                 tflops=round(achieved, 2), mfma_peak_tflops=round(peak, 1), mfma_frac=round(mfma_frac, 4),
                 hbm_gbs=round(hbm_gbs, 1), hbm_frac=round(hbm_frac, 4),
                 issued_tflops=round(achieved * products, 1), frac_of_f32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
