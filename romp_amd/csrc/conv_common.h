@@ -39,6 +39,7 @@ struct ConvParams {
                                  // split-precision kernels only; read back with romp_conv_trace_read, scripts/conv_trace.py)
     int* cu_slots;            // per-CU arrival counters (experiment: phase skew between the workgroups sharing a CU), or nullptr
     int skew;                 // env ROMP_CONV_SKEW: cycles of start delay per arrival slot on a CU (0 = off)
+    float* out2; int out2_cs, out2_co;   // (conv_h2x.hip) the second output tensor
     unsigned in_bytes;        // (fused block kernel) bytes of the input tensor from in + in_co on: num_records of its raw buffer
     int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,

@@ -183,6 +183,16 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(x && y && n->ops[idx - 1].in_buf == op.res_buf, "bblock64: bad buffers %d -> %d", op.res_buf, op.out_buf);
             return launch_bblock64(n->ops[idx - 1], op, x, y, B, queue, st);
         }
+        case ROMP_OP_SEAM1X1: {
+            ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP, "seam1x1: the op before it must be the NOP holding the first conv");
+            const romp_op& a = n->ops[idx - 1];
+            const float* m = resolve_in(n, a.in_buf, image);
+            const float* x = resolve_in(n, a.res_buf, image);
+            float* t = resolve_out(n, a.out_buf, center, params);
+            float* u = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(m && x && t && u && op.in_buf == a.out_buf, "seam1x1: bad buffers");
+            return launch_seam1x1(a, op, m, x, t, u, B, st);
+        }
         case ROMP_OP_NOP:
         case ROMP_OP_FORK:
         case ROMP_OP_JOIN:
@@ -281,6 +291,12 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
     { const int rc = conv_init(); if (rc) return rc; }
+    for (int i = 1; i < n_ops; ++i)
+        if (ops_host[i].kind == ROMP_OP_SEAM1X1) {
+            const int rc = launch_seam1x1(ops_host[i - 1], ops_host[i], nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            if (rc) return rc;
+            break;
+        }
     for (int i = 0, seen = 0; i < n_ops && seen != 3; ++i) {  // the fused blocks' one-time set-up (hipMalloc / attributes) must not run inside a stream capture
         const int kind = ops_host[i].kind;
         if (kind == ROMP_OP_BBLOCK32 && !(seen & 1) && i > 0) {
@@ -670,6 +686,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_NOP) { snprintf(out, n, "nop"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK32) { snprintf(out, n, "bblock32"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK64) { snprintf(out, n, "bblock64"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_SEAM1X1) { snprintf(out, n, "seam1x1"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BEV_PACK) { snprintf(out, n, "bev_pack"); return ROMP_OK; }

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OP_NOP, OP_BBLOCK32, OP_BBLOCK64, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -267,15 +267,52 @@ def assign_formats(P):
 
 
 def pack_h2_wave16(t):
-    """The f16x2 weight pack of a C -> C 3x3 conv (C = 32, 64: [tap 9][C/16][piece 2][k-half 2][cout C][8] int16,
-    pack_conv_weight_h2) re-ordered for csrc/conv_h2c.hip: a wave of channel group cg owns output channels 16 cg .. 16 cg + 15 and
-    reads, per tap, 32-input-channel chunk kc and piece, ONE 16-byte unit per lane -- the A operand of v_mfma_f32_16x16x32_f16:
-    lane = 16 * kq + oc holds input channels 32 kc + 8 kq .. + 7 of output channel 16 cg + oc.
-    -> [group C/16][tap 9][kc C/32][piece 2][lane 64][8] (a pure permutation)."""
-    Cc = t.shape[4]
-    assert tuple(t.shape) == (9, Cc // 16, 2, 2, Cc, 8) and Cc in (32, 64), tuple(t.shape)
-    v = t.reshape(9, Cc // 32, 2, 2, 2, Cc // 16, 16, 8)        # tap, kc, kq / 2, piece, kq % 2, group, oc, 8
-    return v.permute(5, 0, 1, 3, 2, 4, 6, 7).contiguous().reshape(Cc // 16, 9, Cc // 32, 2, 64, 8)
+    """An f16x2 weight pack ([tap T][Cin/16][piece 2][k-half 2][Cout][8] int16, pack_conv_weight_h2; Cin a multiple of 32, Cout of 16)
+    re-ordered for the kernels whose waves own 16-channel groups (csrc/conv_h2c.hip, conv_h2x.hip): per group, tap, 32-input-channel
+    chunk kc and piece ONE 16-byte unit per lane -- the A operand of v_mfma_f32_16x16x32_f16: lane = 16 * kq + oc holds input
+    channels 32 kc + 8 kq .. + 7 of output channel 16 g + oc.  -> [group Cout/16][tap T][kc Cin/32][piece 2][lane 64][8] (a pure
+    permutation)."""
+    T, c16, _, _, Cout, _ = t.shape
+    assert tuple(t.shape) == (T, c16, 2, 2, Cout, 8) and c16 % 2 == 0 and Cout % 16 == 0, tuple(t.shape)
+    v = t.reshape(T, c16 // 2, 2, 2, 2, Cout // 16, 16, 8)       # tap, kc, kq / 2, piece, kq % 2, group, oc, 8
+    return v.permute(5, 0, 1, 3, 2, 4, 6, 7).contiguous().reshape(Cout // 16, T, c16 // 2, 2, 64, 8)
+
+
+def fuse_bottleneck_seams(P):
+    """EXPERIMENTAL, off unless ROMP_FUSE_SEAMS=1 (csrc/conv_h2x.hip: written at the end of round 3, one parity run, not tuned):
+    the last conv of a layer1 Bottleneck (1x1 64 -> 256 + residual + ReLU) and the first conv of the next one (1x1 256 -> 64 + ReLU)
+    as one launch that writes the 256-channel tensor but does not read it back.  -> number of fused seams."""
+    import os
+    P.fused_seams = 0
+    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_SEAMS', '0') != '1' or getattr(P, 'split_k_items', 0):
+        return 0
+    by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
+    for i in range(len(P.ops) - 1):
+        a, b = P.ops[i], P.ops[i + 1]
+        if not (a.kind == OP_CONV and b.kind == OP_CONV):
+            continue
+        ok = (a.ksize == 1 and a.stride == 1 and a.groups == 1 and a.Cin == 64 and a.Cout == 256 and a.cin_pad == 64 and a.cout_pad == 256 and
+              a.relu and a.res_buf >= 0 and a.weight_h2 and a.scale_h2 and
+              b.ksize == 1 and b.stride == 1 and b.groups == 1 and b.Cin == 256 and b.Cout == 64 and b.cin_pad == 256 and b.cout_pad == 64 and
+              b.relu and b.res_buf < 0 and b.weight_h2 and b.scale_h2 and
+              b.in_buf == a.out_buf and (b.in_cstride, b.in_coff) == (a.out_cstride, a.out_coff) and a.stream == b.stream and
+              (a.H, a.W) == (b.H, b.W) and (a.H * a.W) % 64 == 0 and
+              all(o.out_rstride == 0 and o.out_bstride == 0 for o in (a, b)) and
+              a.in_fmt == FMT_H2 and a.res_fmt == FMT_H2 and a.out_fmt == FMT_H2 and b.in_fmt == FMT_H2 and b.out_fmt == FMT_H2 and
+              a.act_shift == b.act_shift)
+        if not ok:
+            continue
+        for o, shape in ((a, (1, 4, 2, 2, 256, 8)), (b, (1, 16, 2, 2, 64, 8))):
+            t = pack_h2_wave16(by_ptr[o.weight_h2].view(*shape))
+            P.consts.append(t)
+            o.weight_aux = t.data_ptr()
+        a.kind, b.kind = OP_NOP, OP_SEAM1X1
+        P.flops[i + 1] += P.flops[i]
+        P.flops[i] = 0.0
+        P.bytes[i + 1] = 4.0 * a.H * a.W * (64 + 256 + 256 + 64)
+        P.bytes[i] = 0.0
+        P.fused_seams += 1
+    return P.fused_seams
 
 
 def fuse_basic_blocks(P):
@@ -573,6 +610,7 @@ class Program:
         if not getattr(self, '_lowered', False):
             assign_formats(self)
             fuse_basic_blocks(self)
+            fuse_bottleneck_seams(self)
             self._lowered = True
         arr = (RompOp * len(self.ops))()
         for i, o in enumerate(self.ops):

@@ -886,3 +886,57 @@ def test_graph_cache_is_bounded(dev):
             keep.append((c, p))                      # keep them alive: every call sees new pointers
         s.synchronize()
     assert all(torch.equal(c, c0) and torch.equal(p, p0) for c, p in keep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H', [(1, 16), (3, 32)])
+def test_seam1x1_experimental(dev, B, H, monkeypatch):
+    """csrc/conv_h2x.hip (EXPERIMENTAL, ROMP_FUSE_SEAMS=1): the 1x1 64 -> 256 (+ residual + ReLU) / 1x1 256 -> 64 (+ ReLU) pair across
+    a Bottleneck seam as one launch: both output tensors against torch on the CPU."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math, decode_h2
+    monkeypatch.setenv('ROMP_FUSE_SEAMS', '1')
+    g = torch.Generator().manual_seed(7 * B + H)
+    x0 = torch.randn(B, H, H, 64, generator=g)
+    dims = [(64, 256), (256, 64), (64, 256), (256, 64), (64, 64)]
+    ws = [torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5 for ci, co in dims]
+    sc = [torch.rand(co, generator=g) + 0.5 for _, co in dims]
+    sh = [torch.randn(co, generator=g) * 0.2 for _, co in dims]
+
+    def cbr(t, i, res=None):
+        y = F.conv2d(t, ws[i], None) * sc[i].view(1, -1, 1, 1) + sh[i].view(1, -1, 1, 1)
+        return torch.relu(y if res is None else y + res)
+    rx = cbr(x0.permute(0, 3, 1, 2), 0)
+    rm = cbr(rx, 1)
+    rt = cbr(rm, 2, res=rx)
+    ru = cbr(rt, 3)
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    ax = P.conv('x', Act(L.BUF_IMAGE, 64, H, H, 64), [ws[0]], [sc[0]], [sh[0]], 1, 1, True)
+    am = P.conv('m', ax, [ws[1]], [sc[1]], [sh[1]], 1, 1, True)
+    at = P.conv('t', am, [ws[2]], [sc[2]], [sh[2]], 1, 1, True, res=ax)
+    au = P.conv('u', at, [ws[3]], [sc[3]], [sh[3]], 1, 1, True)
+    av = P.conv('v', au, [ws[4]], [sc[4]], [sh[4]], 1, 1, True)
+    ops = P.op_array()
+    assert P.fused_seams == 1 and [o.kind for o in P.ops] == [L.OP_CONV, L.OP_CONV, L.OP_NOP, L.OP_SEAM1X1, L.OP_CONV], [o.kind for o in P.ops]
+    lib = L.load()
+    h = C.c_void_p()
+    sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+    L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+    try:
+        xd = x0.to(dev).contiguous()
+        dummy = torch.empty(16, device=dev)
+        L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+        for act, ref, name in ((at, rt, 't'), (au, ru, 'u')):
+            n = P.buf_floats[act.buf] * B
+            out = torch.empty(n, device=dev)
+            L.check(lib.romp_net_read_buffer(h, act.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            y = decode_h2(out.cpu().reshape(B, H, H, act.C))
+            r = ref.permute(0, 2, 3, 1)
+            err = (y - r).abs().max().item() / r.abs().max().item()
+            print(f'seam1x1 B={B} {H}x{H} {name}: relative err {err:.3e}')
+            assert err < 5e-5, (name, err)
+    finally:
+        lib.romp_net_destroy(h)
