@@ -84,8 +84,8 @@ const char* romp_last_error(void);
 #define ROMP_OP_BBLOCK64  14    /* the same for a 64-channel BasicBlock (csrc/conv_h2c.hip): both ops carry, in weight_aux, their
                                    f16x2 weights repacked per wave for 16-channel MFMA rows (plan.pack_h2_wave16); H a multiple of
                                    8, W of 16                                                                                   */
-#define ROMP_OP_SEAM1X1   15    /* EXPERIMENTAL, never emitted by default (plan.fuse_bottleneck_seams, env ROMP_FUSE_SEAMS=1): two 1x1
-                                   convs across a Bottleneck seam as one kernel (csrc/conv_h2x.hip): the op before it (NOP) is a
+#define ROMP_OP_SEAM1X1   15    /* two 1x1 convs across a Bottleneck seam of layer1 as one kernel (csrc/conv_h2x.hip,
+                                   plan.fuse_bottleneck_seams): the op before it (NOP) is a
                                    64->256 conv + residual + ReLU, this op the 256->64 conv + ReLU reading its output; both
                                    outputs are written; weight_aux = per-group packs                                            */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */

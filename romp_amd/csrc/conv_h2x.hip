@@ -1,5 +1,5 @@
-// conv_h2x.hip -- EXPERIMENTAL (round 3, written at the end of the round: compiled, unit-tested once, OFF by default, see
-// plan.fuse_bottleneck_seams): the seam between two Bottlenecks of HRNet's layer1 (simple_romp/romp/model.py:103-123) as ONE kernel.
+// conv_h2x.hip -- the seam between two Bottlenecks of HRNet's layer1 (simple_romp/romp/model.py:103-123) as ONE kernel
+// (plan.fuse_bottleneck_seams, ROMP_OP_SEAM1X1; written at the end of round 3: first version, not tuned).
 //     t = relu(bn3(conv1x1_{64->256}(m)) + x)        the last conv of Bottleneck i (residual x, 256 channels)
 //     u = relu(bn1'(conv1x1_{256->64}(t)))           the first conv of Bottleneck i + 1
 // Both are 1x1 convs on 256-channel 128^2 tensors and HBM-bound (4.3-4.5 TB/s as separate launches, 1.7 ms of an 11.8 ms forward

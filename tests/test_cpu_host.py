@@ -291,6 +291,10 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM:
             written[op.out_buf] = op.out_fmt
+        elif op.kind == L.OP_SEAM1X1:                         # fused Bottleneck seam: writes t (the NOP's output) and u, both H2
+            assert op.in_fmt == L.FMT_H2 and op.out_fmt == L.FMT_H2, name
+            n_h2 += 1
+            written[op.out_buf] = op.out_fmt
         elif op.kind in (L.OP_BBLOCK32, L.OP_BBLOCK64):      # fused BasicBlock: reads x (its residual buffer), writes y, both H2
             assert written.get(op.res_buf) == L.FMT_H2 and op.res_fmt == L.FMT_H2 and op.out_fmt == L.FMT_H2, name
             n_h2 += 1

@@ -890,8 +890,8 @@ def test_graph_cache_is_bounded(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,H', [(1, 16), (3, 32)])
-def test_seam1x1_experimental(dev, B, H, monkeypatch):
-    """csrc/conv_h2x.hip (EXPERIMENTAL, ROMP_FUSE_SEAMS=1): the 1x1 64 -> 256 (+ residual + ReLU) / 1x1 256 -> 64 (+ ReLU) pair across
+def test_seam1x1(dev, B, H, monkeypatch):
+    """csrc/conv_h2x.hip: the 1x1 64 -> 256 (+ residual + ReLU) / 1x1 256 -> 64 (+ ReLU) pair across
     a Bottleneck seam as one launch: both output tensors against torch on the CPU."""
     import ctypes as C
     from romp_amd import lib as L
