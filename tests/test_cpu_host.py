@@ -413,3 +413,29 @@ def test_pack_h2_wave16_is_the_documented_permutation():
     for _ in range(200):
         w, tap, kc, pc, kq, oc, e = (rs.randint(k) for k in (4, 9, 2, 2, 4, 16, 8))
         assert n[w, tap, kc, pc, 16 * kq + oc, e] == t[tap, 2 * kc + kq // 2, pc, kq % 2, 16 * w + oc, e]
+
+
+def test_hrnet_program_fusions_are_the_documented_ones(monkeypatch):
+    """The lowered HRNet-32 program (f16x2, batch plan) fuses exactly what DESIGN.md section 4 says: 32 + 32 BasicBlocks (32- and
+    64-channel) and the 3 Bottleneck seams of layer1; a single-image plan fuses the 32-channel blocks only; ROMP_FUSE_BLOCKS=0 /
+    ROMP_FUSE_SEAMS=0 switch each off.  Every fused op sits right behind the NOP that carries its first conv."""
+    from romp_amd import lib as L, synthetic as S
+    from romp_amd.plan import build_romp_hrnet32
+    sd = S.make_romp_state_dict(0)
+
+    def kinds(**kw):
+        P = build_romp_hrnet32(sd, 'cpu', 512, bf16x3='f16x2', **kw)
+        P.op_array()
+        ks = [op.kind for op in P.ops]
+        for i, k in enumerate(ks):
+            if k in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1):
+                assert ks[i - 1] == L.OP_NOP, (i, P.names[i])
+        return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), ks.count(L.OP_SEAM1X1), ks.count(L.OP_NOP)
+    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_BBLOCK32'):
+        monkeypatch.delenv(v, raising=False)
+    assert kinds() == (32, 32, 3, 67)
+    assert kinds(split_k_items=256) == (32, 0, 0, 32)
+    monkeypatch.setenv('ROMP_FUSE_BLOCKS', '0')
+    assert kinds() == (0, 0, 3, 3)
+    monkeypatch.setenv('ROMP_FUSE_SEAMS', '0')
+    assert kinds() == (0, 0, 0, 0)
