@@ -282,10 +282,11 @@ def fuse_bottleneck_seams(P):
     """Peephole like fuse_basic_blocks (csrc/conv_h2x.hip, ROMP_OP_SEAM1X1): the last conv of a layer1 Bottleneck (1x1 64 -> 256 +
     residual + ReLU, model.py:103-123) and the first conv of the next one (1x1 256 -> 64 + ReLU) as one launch that writes the
     256-channel tensor (the next block's residual) but does not read it back: 1.87 -> 1.34 GB per seam at B = 32, 2 709 -> 2 802
-    images/s.  Batch plans; env ROMP_FUSE_SEAMS=0 switches it off (A/B runs).  -> number of fused seams."""
+    images/s.  Batch plans (single-image plans: no measurable difference, 2.22-2.48 vs 2.33-2.35 ms per frame); env ROMP_FUSE_SEAMS=0
+    switches it off, =all also fuses in single-image plans (A/B runs).  -> number of fused seams."""
     import os
     P.fused_seams = 0
-    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_SEAMS', '1') != '1' or getattr(P, 'split_k_items', 0):
+    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_SEAMS', '1') not in ('1', 'all') or (getattr(P, 'split_k_items', 0) and os.environ.get('ROMP_FUSE_SEAMS', '1') != 'all'):
         return 0
     by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
     for i in range(len(P.ops) - 1):
