@@ -1,12 +1,16 @@
 // stem_fuse.hip -- the two non-GEMM layer kernels of the network:
 //   * stem conv1: input normalisation x/255*2-1 (model.py:384) fused into the 3->64 3x3 stride-2
-//     convolution + BN + ReLU (model.py:385-387).  K = 27 is too thin for the matrix cores and the
-//     layer is bound by its 16.8 MB/image output, so it is a VALU kernel whose stores are laid out
-//     for 1 KiB contiguous runs (4 adjacent pixels x 64 channels per store instruction).
+//     convolution + BN + ReLU (model.py:385-387).  Two kernels: stem_conv_kernel (VALU, float32 products: the float32 /
+//     calibration programs) and stem_mfma_kernel (K = 27 padded to one 32-wide f16x2 MFMA step, H2 output: the default path;
+//     the VALU form was instruction-bound at 0.33 ms for 0.12 ms worth of HBM traffic).
 //   * fuse-sum: y_i = relu(sum_j up_nearest(T_j))  (HighResolutionModule.forward model.py:233-244)
 //     -- replaces the reference's nearest-upsample kernels and the chain of adds with one pass that
 //     reads each term once and writes y once.  Summation order is the reference's (j ascending).
 #include "conv_common.h"      // h2_pack / h2_unpack: the H2 activation format
+#include "conv_split.h"       // f16x8
+#include "conv_fuse.h"        // h2_low_pair
+#include <stdlib.h>
+#include <string.h>
 
 namespace romp {
 
@@ -102,6 +106,129 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     }
 }
 
+// The same layer on the matrix cores (round 3, H2 output only): the VALU kernel above is instruction-bound (1 728 FMAs per thread,
+// SQ_ACTIVE_INST_ANY 69 % of its wave cycles, 0.33 ms for 0.12 ms worth of HBM traffic at B = 32).  K = 27 pads to ONE 32-wide MFMA
+// step: v_mfma_f32_16x16x32_f16 with A = 16 output channels x (tap, colour) as fp16 pairs of 256 w (registers, split once per
+// workgroup) and B = the im2col column of a pixel, gathered from the normalised halo in LDS and split into fp16 pairs of 16 x on the
+// fly -- the three f16x2 products, float32 accumulate, like every other conv.  Lane (px, kq) gathers k = 8 kq .. 8 kq + 7 of pixel
+// px of a 16-pixel row block once for all 64 output channels (4 groups x 3 products = 12 MFMAs per gather); k = 27 .. 31 read any
+// valid halo value against zero weights.  Wave w: rows 4 w .. 4 w + 3 of the 16 x 16 tile.
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p) {
+    constexpr int T = 16, HS = 2 * T + 1;
+    using frag = f16x8;
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) float s_in[HS * HS * 3];
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x; bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const float* img = p.image + (size_t)b * p.H * p.W * 3;
+    const int iy0 = ty * T * 2 - 1, ix0 = tx * T * 2 - 1;
+    {   // halo fill, branch-free and batched (see stem_conv_kernel)
+        constexpr int NL = (HS * HS * 3 + 255) / 256;
+        float raw[NL];
+        bool ok[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;
+            const int idc = idx < HS * HS * 3 ? idx : 0;
+            const int e = idc % (HS * 3), hy = idc / (HS * 3);
+            const int iy = iy0 + hy, ix = ix0 + e / 3;
+            ok[k] = idx < HS * HS * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            raw[k] = img[ok[k] ? ((size_t)iy * p.W + ix0) * 3 + e : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;               // zero padding is applied AFTER normalisation; x 16: the fp16 pieces' scale
+            if (idx < HS * HS * 3) s_in[idx] = ok[k] ? ((raw[k] / 255.0f) * 2.0f - 1.0f) * 16.0f : 0.f;
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 15, q = lane >> 4;
+    auto pack_hi = [&](float a, float c) __attribute__((always_inline)) {
+        const f32x2_t v = {a, c};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+    };
+    // this lane's 8 k indices -> offsets into the halo (floats, relative to the pixel's top-left tap) ...
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j < 27 ? 8 * q + j : 26;
+        const int tap = k / 3, ci = k % 3;
+        koff[j] = ((tap / 3) * HS + tap % 3) * 3 + ci;
+    }
+    // ... and the A operands: channel 16 g + px, the same 8 k (zero beyond 26), 256 w split into fp16 pairs
+    frag wa[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k0 = 8 * q + 2 * jj, k1 = k0 + 1;
+            const float w0 = k0 < 27 ? h2_sat(p.w[k0 * 64 + 16 * g + px] * 256.0f) : 0.f;
+            const float w1 = k1 < 27 ? h2_sat(p.w[k1 * 64 + 16 * g + px] * 256.0f) : 0.f;
+            hi[jj] = pack_hi(w0, w1);
+            lo[jj] = h2_low_pair(hi[jj], w0, w1);
+        }
+        wa[g][0] = __builtin_bit_cast(frag, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+        wa[g][1] = __builtin_bit_cast(frag, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    }
+    __syncthreads();
+
+    f32x4s acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[r][g] = (f32x4s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float* base = s_in + ((2 * (4 * wave + r)) * HS + 2 * px) * 3;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = base[koff[j]];
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            hi[jj] = pack_hi(x[2 * jj], x[2 * jj + 1]);
+            lo[jj] = h2_low_pair(hi[jj], x[2 * jj], x[2 * jj + 1]);
+        }
+        const frag xh = __builtin_bit_cast(frag, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+        const frag xl = __builtin_bit_cast(frag, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][1], xh, acc[r][g], 0, 0, 0);
+            acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][0], xl, acc[r][g], 0, 0, 0);
+            acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][0], xh, acc[r][g], 0, 0, 0);
+        }
+    }
+    // epilogue: lane (px, q) holds channels 16 g + 4 q .. + 3 of pixel px of row block r: BN + ReLU in the scaled domain, split, the
+    // lanes of an octet trade halves (v_permlane16_swap) and each stores one 16-byte unit
+    const float prod_scale = p.act_scale * (1.0f / 4096.0f);
+    float* out = p.out + (size_t)b * p.Ho * p.Wo * p.out_cs + p.out_co + ((size_t)(ty * T + 4 * wave) * p.Wo + tx * T + px) * p.out_cs + 4 * q;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + 16 * g + 4 * q);
+        const float4 sh = *reinterpret_cast<const float4*>(p.shift + 16 * g + 4 * q);
+        const float s4[4] = {sc.x * prod_scale, sc.y * prod_scale, sc.z * prod_scale, sc.w * prod_scale};
+        const float b4[4] = {sh.x * p.act_scale, sh.y * p.act_scale, sh.z * p.act_scale, sh.w * p.act_scale};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h2_sat(fmaxf(fmaf(acc[r][g][e], s4[e], b4[e]), 0.f));
+            unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
+            unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
+            const u32x2_t a = __builtin_amdgcn_permlane16_swap(hh[0], hl[0], false, false);
+            const u32x2_t c = __builtin_amdgcn_permlane16_swap(hh[1], hl[1], false, false);
+            *reinterpret_cast<uint4*>(out + (size_t)r * p.Wo * p.out_cs + 16 * g) = make_uint4(a[0], c[0], a[1], c[1]);
+        }
+    }
+}
+
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st) {
     ROMP_REQUIRE(op.Cin == 3 && op.Cout == 64 && op.ksize == 3 && op.stride == 2, "stem: expects 3->64 k3 s2");
     ROMP_REQUIRE(op.H % 32 == 0 && op.W % 32 == 0, "stem: input %dx%d must be a multiple of 32", op.H, op.W);
@@ -113,7 +240,10 @@ int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStr
     p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.act_scale = ldexpf(1.f, op.act_shift);
     ROMP_REQUIRE(!p.out_h2 || ((op.out_cstride | op.out_coff) & 7) == 0, "stem: H2 output needs octet-aligned channels");
     p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 16;
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
+    static int use_mfma = -1;                                  // env ROMP_STEM=valu: the VALU kernel for the H2 output too (A/B runs)
+    if (use_mfma < 0) { const char* e = getenv("ROMP_STEM"); use_mfma = (e && !strcmp(e, "valu")) ? 0 : 1; }
+    if (p.out_h2 && use_mfma) hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

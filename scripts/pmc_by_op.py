@@ -15,8 +15,8 @@ import re
 import sys
 from collections import defaultdict
 
-NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|stem_conv_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
-FIRST = ('stem_conv_kernel', 'stem7_conv_kernel')
+NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|stem_conv_kernel|stem_mfma_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
+FIRST = ('stem_conv_kernel', 'stem_mfma_kernel', 'stem7_conv_kernel')
 
 
 def kernel_of(variant_name):
