@@ -236,6 +236,11 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
 
 // the (zeroed) stamp buffer for a kernel launched outside launch_conv (the fused BasicBlock), or nullptr when tracing is off
 unsigned long long* conv_trace_arm(hipStream_t st) {
+    {   // never allocate or memset inside a stream capture (the fused kernels call this from their launch path): tracing is a
+        // debugging aid for eager launches (romp_net_profile, romp_conv_forward)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+    }
     if (!g_trace) {
         const char* e = getenv("ROMP_CONV_TRACE");
         if (!(e && atoi(e))) return nullptr;
