@@ -6,17 +6,21 @@
 // read once (haloed), y written once, and the intermediate m never leaves the CU.
 //
 // One 256-thread workgroup per CU -- ONE wave per SIMD, so each wave owns the SIMD's whole 512-entry register file -- persistent
-// over 16x16-pixel output tiles.  Every wave keeps the split weights of BOTH convs in registers for the whole launch (2 x 144
-// VGPRs: no weight traffic after the prologue).  Per tile:
+// over 16x16-pixel output tiles.  Every wave keeps the split weights of BOTH convs in registers for the whole launch (2 x 144:
+// conv1's pinned to AGPRs, which MFMA reads directly; no weight traffic after the prologue).  Per tile:
 //   1. conv1 on the tile's 18x18 halo of m (11 blocks of 32 pixels: nine 2-row x 16-column blocks and two blocks holding the
-//      edge columns; 3 block slots per wave) from the 20x20 input halo of x, which arrived by LDS-DMA (both 16-channel chunks)
-//      while the previous tile was in steps 3-4; the residual rows of this tile are loaded into registers first;
-//   2. barrier; the DMA of the NEXT tile's halo is issued (it has steps 3 and 4 to land); bn1 + ReLU, ZERO outside the image
-//      (conv2's padding), pre-split, written into LDS in the rotated unit layout the fragment reads use; barrier;
-//   3. conv2 from m in LDS (two blocks per wave);
-//   4. the ordinary fused epilogue (bn2 + x + ReLU, H2 stores); drain; barrier.
-// With one wave per SIMD nothing hides a wave's own stalls, so the fragment reads run three block-steps ahead of their MFMAs
-// (registers are not scarce here) and the only waits on memory sit at the two ends of a tile.
+//      edge columns; 3 block slots per wave) from the 20x20 input halo of x, which arrived by raw-buffer LDS-DMA (both 16-channel
+//      chunks) under the previous tile's conv2.  Under slot 0's MFMAs: the finish of the PREVIOUS tile's second output block and
+//      the parking of this tile's residual pieces (LDS halo -> per-lane LDS slots); under slot s: the hand-over of slot s - 1
+//      (bn1 + ReLU, ZERO outside the image = conv2's padding, pre-split, into LDS in the rotated unit layout the fragment reads
+//      use).  The last slot's hand-over is the one tail; barrier;
+//   2. conv2 from m in LDS (two blocks per wave).  Under block 0: the DMA of the NEXT tile's halo; under block 1: the finish of
+//      block 0 (bn2 + x + ReLU in the scaled domain, split, v_permlane32_swap, 16-byte stores); drain; barrier.
+// With one wave per SIMD nothing hides a wave's own stalls and the wave issues in order: every kind of side work is cut into
+// micro-steps of a few instructions, one behind each MFMA, pinned there (sched_barrier); table reads are issued an LDS round trip
+// ahead of their use.  History and measurements: profiles/r03_fused_blocks_notes.md.  Batch plans run the 32-channel blocks on
+// conv_h2c.hip's row-pipelined kernel instead (launch_bblock32 hands over when the ops carry per-wave weight packs); this kernel
+// serves single-image plans and ROMP_BBLOCK32=v1.
 #include "conv_split.h"
 #include "conv_fuse.h"
 #include <string.h>
