@@ -37,7 +37,7 @@ extern "C" {
 #define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
 #define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
 
-#define ROMP_ABI_VERSION 4
+#define ROMP_ABI_VERSION 5
 
 int         romp_abi_version(void);
 const char* romp_last_error(void);
@@ -90,6 +90,13 @@ const char* romp_last_error(void);
                                    outputs are written; weight_aux = per-group packs                                            */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
+/* romp_op.flags */
+#define ROMP_OPF_WAVE16     1   /* weight_aux holds the f16x2 weights repacked per wave for 16-channel MFMA rows
+                                   (plan.pack_h2_wave16: BBLOCK64, SEAM1X1 and the row-pipelined BBLOCK32 kernel), not a
+                                   bf16x3 pack: the fused kernels dispatch on this bit, never on weight_aux != NULL   */
+#define ROMP_OPF_STEM_VALU  2   /* STEM: take the float32 VALU kernel even for an H2 output (A/B runs, tests; also chosen
+                                   when 256 * |w| does not fit the fp16 pieces of the MFMA form)                      */
+
 typedef struct romp_op {
     int32_t kind;
     int32_t in_buf, out_buf, res_buf;
@@ -116,6 +123,12 @@ typedef struct romp_op {
     int32_t act_shift;            /* CONV, f16x2 kernels: activations are multiplied by 2^act_shift before they are split
                                      into fp16 pieces (keeps the low piece out of the fp16 subnormal range; |x| must stay
                                      below 65504 / 2^act_shift).  scale_h2 carries the inverse.                       */
+    int32_t flags;                /* ROMP_OPF_* bits                                                                  */
+    int32_t relu_from;            /* CONV with relu != 0: ReLU applies to output channels >= relu_from only (0: all).
+                                     Sibling convs that read one tensor run as ONE conv with concatenated output channels
+                                     (plan.merge_sibling_convs): the fuse layers' stride-2 chains (model.py:198-221) mix a
+                                     last conv (no ReLU) with first convs (ReLU).  A multiple of 32.                  */
+    int32_t term_coff[4];         /* FUSESUM: channel offset of each term inside its buffer (a slice of a merged conv's output) */
     const float* weight;          /* packed [group][chunk][tap][cin/4][cout_pad][4]       */
     const float* scale;           /* [group][cout_pad]  gamma/sqrt(var+eps)  (or 1)       */
     const float* shift;           /* [group][cout_pad]  beta-mean*scale (+scale*bias)     */
@@ -175,11 +188,20 @@ int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* cent
                       float* params_maps_nhwc, void* stream, float* ms_out_host, int iters);
 /* Activation range scan (f16x2 range safety): runs the program op by op on `stream` and reports, for every op that writes an
  * arena buffer, max|x| (maxabs_out_host[n_ops]; H2 tensors decoded) and the number of non-finite values
- * (nonfinite_out_host[n_ops]) of that buffer's B images right after the op; 0 for ops without an arena output.  The host
- * (plan.assign_formats) keeps tensors whose range does not fit the fp16 pieces of ROMP_FMT_H2 in float32 and their consumers on
- * the f32 / bf16x3 kernels; the kernels themselves saturate at +-65504 instead of producing inf / NaN pieces.  Synchronises. */
+ * (nonfinite_out_host[n_ops]) of the REGION the op wrote (its pixels x channel slice of B images) right after the op; 0 for ops
+ * without an arena output.  saturated_out_host[n_ops] (may be NULL): saturation events each op reported (see romp_net_saturated;
+ * the fused-block kernels run their counting builds during a scan).  The host (plan.assign_formats) keeps tensors whose range
+ * does not fit the fp16 pieces of ROMP_FMT_H2 in float32 and their consumers on the f32 / bf16x3 kernels; the kernels themselves
+ * saturate at +-65504 instead of producing inf / NaN pieces.  Synchronises. */
 int  romp_net_range_scan(romp_net* net, const float* image_nhwc, int B, float* center_maps, float* params_maps_nhwc,
-                         void* stream, float* maxabs_out_host, int32_t* nonfinite_out_host);
+                         void* stream, float* maxabs_out_host, int32_t* nonfinite_out_host, int32_t* saturated_out_host);
+/* Saturation is observable: every kernel that splits values into the fp16 pieces of ROMP_FMT_H2 clamps at +-65504 / 2^act_shift
+ * and reports a clamp into the net's device counter (one increment per wave and work item).  *count_host = events since
+ * romp_net_create or the last call with reset != 0; 0 for a net inside its calibrated range.  The two register-resident
+ * fused BasicBlock kernels count only in their checked builds: romp_net_set_sat_check(net, 1) (default: env ROMP_CHECK_FINITE=1)
+ * and every romp_net_range_scan.  romp_net_saturated synchronises `stream`. */
+int  romp_net_saturated(romp_net* net, int64_t* count_host, int reset, void* stream);
+int  romp_net_set_sat_check(romp_net* net, int enable);
 void romp_net_destroy(romp_net* net);
 
 /* Stand-alone conv launcher (tests / microbenchmarks of one layer).  variant < 0: heuristic. */

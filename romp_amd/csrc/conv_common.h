@@ -41,6 +41,9 @@ struct ConvParams {
     int skew;                 // env ROMP_CONV_SKEW: cycles of start delay per arrival slot on a CU (0 = off)
     float* out2; int out2_cs, out2_co;   // (conv_h2x.hip) the second output tensor
     unsigned in_bytes;        // (fused block kernel) bytes of the input tensor from in + in_co on: num_records of its raw buffer
+    int relu_from;            // relu != 0: ReLU on output channels >= relu_from only (romp_op.relu_from; a multiple of 32)
+    int* sat;                 // saturation counter of the running net (conv_sat_counter(), may be nullptr): +1 per wave and work item that
+                              // clamped a value at +-65504 while splitting it into fp16 pieces (h2_sat): out-of-calibration activations
     int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
                               // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
@@ -61,9 +64,20 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 // activation ranges (plan.assign_formats, romp_net_range_scan), the clamp is what keeps an unforeseen outlier finite.
 constexpr float H2_MAX = 65504.f;
 __device__ __forceinline__ float h2_sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, -H2_MAX), H2_MAX); }
+// Saturation is OBSERVABLE: every site that clamps keeps a per-lane running max of |value before the clamp| (one
+// v_max3_f32 per two values) and reports once per wave and work item -- sat_report -- into the net's device counter
+// (romp_net_saturated; RompNet.saturated).  The two register-resident fused-block kernels (conv_h2b / conv_h2c.hip), whose side work
+// is placed instruction by instruction, count in their checked builds only (romp_net_range_scan and ROMP_CHECK_FINITE=1 run those).
+__device__ __forceinline__ void sat_track(float& mx, float a, float b) { mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
+__device__ __forceinline__ void sat_report(int* counter, float mx) {
+    if (counter && __builtin_amdgcn_ballot_w64(mx >= H2_MAX) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1);
+}
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo) {
-    const float x[4] = {h2_sat(v.x * act_scale), h2_sat(v.y * act_scale), h2_sat(v.z * act_scale), h2_sat(v.w * act_scale)};
+__device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo, float& mx) {
+    const float s[4] = {v.x * act_scale, v.y * act_scale, v.z * act_scale, v.w * act_scale};
+    sat_track(mx, s[0], s[1]);
+    sat_track(mx, s[2], s[3]);
+    const float x[4] = {h2_sat(s[0]), h2_sat(s[1]), h2_sat(s[2]), h2_sat(s[3])};
     f16x4 h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -72,6 +86,10 @@ __device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, ui
     }
     hi = __builtin_bit_cast(uint2, h);
     lo = __builtin_bit_cast(uint2, l);
+}
+__device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo) {
+    float mx = 0.f;
+    h2_pack(v, act_scale, hi, lo, mx);
 }
 __device__ __forceinline__ float4 h2_unpack(uint2 hi, uint2 lo, float inv_act_scale) {
     const f16x4 h = __builtin_bit_cast(f16x4, hi), l = __builtin_bit_cast(f16x4, lo);
@@ -195,7 +213,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
     using C = ConvCfg<KS, S, MT, NT, TW, CK, NWV>;
     float* out = p.out + (size_t)cur.b * p.out_bs + p.out_co + cur.g * p.out_gs;
     const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs : nullptr;
-    const float floor_v = p.relu ? 0.f : -__builtin_inff();
+    // ReLU is a max with 0 or -inf, per 32-channel block: a merged conv (romp_op.relu_from) mixes blocks with and without it
+    auto floor_of = [&](int co) { return (p.relu && co >= p.relu_from) ? 0.f : -__builtin_inff(); };
+    float sat_mx = 0.f;
     if (p.vec_io) {
         const int lane = lh * 32 + li;
         const int oc = lane & 3;                      // channel octet of the 32-channel block this lane stores
@@ -235,6 +255,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
+                const float floor_v = floor_of(cur.n0 + n * 32);
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int cl = n * 32 + g4 * 8 + lh * 4;
@@ -268,8 +289,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                     float* op_ = out + (outo[m][j] + (unsigned)(cur.n0 + n * 32 + oc * 8));
                     if (p.out_h2) {
                         uint2 ha, la, hb, lb;
-                        h2_pack(va, p.act_scale, ha, la);
-                        h2_pack(vb, p.act_scale, hb, lb);
+                        h2_pack(va, p.act_scale, ha, la, sat_mx);
+                        h2_pack(vb, p.act_scale, hb, lb, sat_mx);
                         va = __builtin_bit_cast(float4, make_uint4(ha.x, ha.y, hb.x, hb.y));      // high unit
                         vb = __builtin_bit_cast(float4, make_uint4(la.x, la.y, lb.x, lb.y));      // low unit
                     }
@@ -280,6 +301,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        if (p.out_h2) sat_report(p.sat, sat_mx);
     } else {
         // scalar path: output convs of the head (Cout = 142 / 1 / 3 into unaligned NHWC slots)
         unsigned pixo[MT], outo[MT];
@@ -305,7 +327,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                         if (co + e < p.Cout && rowok[m]) {
                             float t = fmaf(acc[m][n][g4 * 4 + e], sSc[cl + e], sSc[C::NW + cl + e]);
                             if (res) t += res[pixo[m] * (unsigned)p.res_cs + (unsigned)(co + e)];
-                            out[outo[m] + (unsigned)(co + e)] = fmaxf(t, floor_v);
+                            out[outo[m] + (unsigned)(co + e)] = fmaxf(t, floor_of(co + e));
                         }
                     }
                 }

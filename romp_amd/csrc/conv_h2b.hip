@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     // a VALU instruction 4) and one step follows each MFMA, pinned there with a scheduling barrier.
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
     f32x16 acc2[2];                                            // (block 1's outlives its tile: finished under the next tile's conv1)
+    float sat_mx = 0.f;                                        // (DBG & 16, the checked build) largest value handed to a split: == H2_MAX iff clamped
     Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
                 const int e = w == 1 ? 0 : w == 3 ? 1 : w == 7 ? 2 : 3;
                 const unsigned wh = e < 2 ? e_rh.x : e_rh.y, wl = e < 2 ? e_rl.x : e_rl.y;
                 ev[e] = (e & 1) ? add_pieces_relu<1>(ev[e], wh, wl, H2_MAX) : add_pieces_relu<0>(ev[e], wh, wl, H2_MAX);
+                if ((DBG & 16) && live) sat_mx = fmaxf(sat_mx, ev[e]);      // (not live: the first tile's pass over a block that does not exist)
                 if (w == 9 && g4 < 3) prep(g4 + 1);            // the tables are free: the next group's reads go out now
                 break; }
             case 4: split_a(ev[0], ev[1], eh[0]); break;
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             case 0: case 1: case 4: case 5: {
                 const int e = w < 2 ? w : w - 2;
                 const float a = h2_sat(fmaxf(fmaf(acc1[sl][g4 * 4 + e], h_sc[e], h_sh[e]), 0.f));
+                if ((DBG & 16) && h_in) sat_mx = fmaxf(sat_mx, a);
                 hv[e] = h_in ? a : 0.f;
                 if (w == 5 && g4 < 3) prep(g4 + 1);            // the tables are free: the next group's reads go out now
                 break; }
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) ev[e] = fmaxf(fmaf(acc2[1][g4 * 4 + e], e_sc[e], e_sh[e]) + ((float)rh[e] + (float)rl[e]), 0.f);
             unsigned eh[2], el[2];
+            if (DBG & 16) { sat_track(sat_mx, ev[0], ev[1]); sat_track(sat_mx, ev[2], ev[3]); }
             split2(ev[0], ev[1], eh[0], el[0]);
             split2(ev[2], ev[3], eh[1], el[1]);
             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -471,15 +475,17 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             *reinterpret_cast<uint4*>(o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
     }
+    if (DBG & 16) sat_report(p.sat, sat_mx);
 #undef SIDE_PIN
 }
 
 // `op` is the block's SECOND conv (its residual is the block input x, its output y); `op1` the first (weights / scale / shift).
 int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
     {   // two implementations: this file's (v1: 16x16 tiles, one wave per SIMD) and conv_h2c.hip's row-pipelined one (two waves per SIMD)
-        static int use_r = -1;
-        if (use_r < 0) { const char* e = getenv("ROMP_BBLOCK32"); use_r = (e && !strcmp(e, "v1")) ? 0 : 1; }   // default: the row-pipelined kernel
-        if (use_r && op1.weight_aux && op.weight_aux && op.H % 8 == 0) return launch_bblock32r(op1, op, x, y, B, queue, st);
+        // The plan decides (plan.fuse_basic_blocks; env ROMP_BBLOCK32=v1 there keeps this file's kernel everywhere): the row-pipelined
+        // kernel needs the per-wave weight packs, announced by ROMP_OPF_WAVE16 -- weight_aux alone may just as well be the bf16x3 pack
+        // of conv_math='all' (a single-image 'all' plan ran the row kernel on bf16x3 bytes).
+        if ((op1.flags & op.flags & ROMP_OPF_WAVE16) && op.H % 8 == 0) return launch_bblock32r(op1, op, x, y, B, queue, st);
     }
     ROMP_REQUIRE(op.ksize == 3 && op.stride == 1 && op.Cin == 32 && op.Cout == 32 && op.cin_pad == 32 && op.cout_pad == 32 && op.groups == 1 &&
                  op1.ksize == 3 && op1.stride == 1 && op1.Cin == 32 && op1.Cout == 32 && op1.cin_pad == 32 && op1.cout_pad == 32 && op1.groups == 1,
@@ -495,6 +501,7 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     static int num_cu = 256;
     using KernelFn = void (*)(ConvParams);
     static KernelFn fn = bblock32_kernel<0>;
+    const KernelFn fn_checked = bblock32_kernel<16>;            // the build that counts clamped values (conv_common.h sat_report)
     if (!attr) {                                               // (romp_net_create calls this path's setup outside any stream capture: bblock_init)
         const char* e = getenv("ROMP_CONV_DEBUG");
         switch (e ? atoi(e) : 0) {
@@ -509,6 +516,7 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
             default: ROMP_REQUIRE(false, "bblock32: ROMP_CONV_DEBUG is one of 0 1 2 4 7 8 15 71 here");
         }
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
+        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_checked), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
         ROMP_HIP_CHECK(hipMalloc((void**)&zero, 256));
         ROMP_HIP_CHECK(hipMemset(zero, 0, 256));
         int dev = 0;
@@ -532,6 +540,8 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     p.in_h2 = p.out_h2 = p.res_h2 = 1;
     p.queue = queue;
     p.trace = conv_trace_arm(st);
+    p.sat = conv_sat_counter();
+    const bool checked = conv_sat_checked() && p.sat && fn == static_cast<KernelFn>(bblock32_kernel<0>);
     {
         const unsigned long long bytes = ((unsigned long long)B * op.H * op.W * op1.in_cstride - op1.in_coff) * 4ull;
         ROMP_REQUIRE(bytes < 0x80000000ull, "bblock32: input tensor of %llu bytes: beyond the 31-bit offsets of the halo fetch", bytes);
@@ -555,7 +565,7 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     long grid = num_cu;                                        // one workgroup per CU
     if (grid > p.tiles_total) grid = p.tiles_total;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), BCfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(checked ? fn_checked : fn, dim3((unsigned)grid), dim3(256), BCfg::LDS_BYTES, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

@@ -62,7 +62,9 @@ struct RCfg {
 
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 
-// DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / parking, 4 no finish, 8 no MFMA
+// DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / parking, 4 no finish, 8 no MFMA;
+// 16: the CHECKED build (correct outputs): also counts values clamped at +-65504 on their way into fp16 pieces (conv_common.h
+// sat_report; romp_net_range_scan and ROMP_CHECK_FINITE=1 run it -- two more VALU per four values of side work)
 template <int C, int DBG>
 __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvParams p) {
     using X = RCfg<C>;
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
 
     f32x4c acc2[X::THW];                                        // (the last row's outlives its tile: finished under the next tile's first MFMAs)
+    float sat_mx = 0.f;                                         // (DBG & 16) largest value handed to a split: == H2_MAX iff clamped
     Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
                 const unsigned wh = e < 2 ? e_rh.x : e_rh.y, wl = e < 2 ? e_rl.x : e_rl.y;
                 const float v = fmaf(acc2[r][e], s2[e], b2[e]);
                 ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
+                if ((DBG & 16) && live) sat_mx = fmaxf(sat_mx, ev[e]);      // (not live: the first tile's pass over a row that does not exist)
                 break; }
             case 5: eh[0] = pack_hi(ev[0], ev[1]); eh[1] = pack_hi(ev[2], ev[3]); break;
             case 6: el[0] = h2_low_pair(eh[0], ev[0], ev[1]); el[1] = h2_low_pair(eh[1], ev[2], ev[3]); break;
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #pragma unroll
                 for (int e = 2 * t; e < 2 * t + 2; ++e) {
                     const float v = h2_sat(fmaxf(fmaf(a[e], s1[e], b1[e]), 0.f));
+                    if ((DBG & 16) && inside) sat_mx = fmaxf(sat_mx, v);
                     hv[e] = inside ? v : 0.f;
                 }
                 break; }
@@ -454,6 +459,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
             const unsigned wh = e < 2 ? rh.x : rh.y, wl = e < 2 ? rl.x : rl.y;
             const float v = fmaf(acc2[r][e], s2[e], b2[e]);
             ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
+            if (DBG & 16) sat_mx = fmaxf(sat_mx, ev[e]);
         }
         unsigned eh[2] = {pack_hi(ev[0], ev[1]), pack_hi(ev[2], ev[3])};
         unsigned el[2] = {h2_low_pair(eh[0], ev[0], ev[1]), h2_low_pair(eh[1], ev[2], ev[3])};
@@ -464,6 +470,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
         float* o = p.out + (size_t)itp.b * p.out_bs + p.out_co + (unsigned)((oy * p.out_rs + ox * p.out_cs) + (16 * cg + 4 * q));
         *reinterpret_cast<uint4*>(o) = make_uint4(a[0], b[0], a[1], b[1]);
     }
+    if (DBG & 16) sat_report(p.sat, sat_mx);
 #undef SIDE_PIN
 }
 
@@ -475,7 +482,8 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     ROMP_REQUIRE(op.ksize == 3 && op.stride == 1 && op.Cin == C && op.Cout == C && op.groups == 1 &&
                  op1.ksize == 3 && op1.stride == 1 && op1.Cin == C && op1.Cout == C && op1.groups == 1,
                  "bblock%d: two 3x3 stride-1 %d -> %d convs expected", C, C, C);
-    ROMP_REQUIRE(op1.weight_aux && op1.scale_h2 && op.weight_aux && op.scale_h2 && op1.relu && op.relu, "bblock%d: per-wave f16x2 weight packs and ReLUs expected", C);
+    ROMP_REQUIRE(op1.weight_aux && op1.scale_h2 && op.weight_aux && op.scale_h2 && (op1.flags & op.flags & ROMP_OPF_WAVE16) && op1.relu && op.relu,
+                 "bblock%d: per-wave f16x2 weight packs (ROMP_OPF_WAVE16) and ReLUs expected", C);
     ROMP_REQUIRE(op1.in_fmt == ROMP_FMT_H2 && op.res_fmt == ROMP_FMT_H2 && op.out_fmt == ROMP_FMT_H2 && op1.act_shift == op.act_shift,
                  "bblock%d: H2 tensors expected", C);
     ROMP_REQUIRE(op.H % X::TH == 0 && op.W % X::TW == 0 && op1.H == op.H && op1.W == op.W, "bblock%d: %dx%d is not a multiple of the 8x16 tile", C, op.H, op.W);
@@ -485,6 +493,7 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     static int num_cu = 256;
     using KernelFn = void (*)(ConvParams);
     static KernelFn fn = bblockr_kernel<C, 0>;
+    const KernelFn fn_checked = bblockr_kernel<C, 16>;
     if (!attr) {                                               // (romp_net_create calls this path's set-up outside any stream capture)
         const char* e = getenv("ROMP_CONV_DEBUG");
         switch (e ? atoi(e) : 0) {
@@ -497,6 +506,7 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
             default: ROMP_REQUIRE(false, "bblock%d: ROMP_CONV_DEBUG is one of 0 1 2 4 7 8 here", C);
         }
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
+        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_checked), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
         int dev = 0;
         hipDeviceProp_t prop;
         ROMP_HIP_CHECK(hipGetDevice(&dev));
@@ -517,6 +527,8 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     p.in_h2 = p.out_h2 = p.res_h2 = 1;
     p.queue = queue;
     p.trace = conv_trace_arm(st);
+    p.sat = conv_sat_counter();
+    const bool checked = conv_sat_checked() && p.sat && fn == static_cast<KernelFn>(bblockr_kernel<C, 0>);
     {
         const unsigned long long bytes = ((unsigned long long)B * op.H * op.W * op1.in_cstride - op1.in_coff) * 4ull;
         ROMP_REQUIRE(bytes < 0x80000000ull, "bblock%d: input tensor of %llu bytes: beyond the 31-bit offsets of the halo fetch", C, bytes);
@@ -540,7 +552,7 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     long grid = (long)num_cu * X::WG_PER_CU;
     if (grid > p.tiles_total) grid = p.tiles_total;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(checked ? fn_checked : fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

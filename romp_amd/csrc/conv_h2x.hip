@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
     const int xa = (2 * q * X::N + px) * 16;                    // GEMM 1 fragment: + ((8 kc + pc) * 64 + 16 pb) * 16
     const int ta = X::OFF_T + (2 * q * X::N + px) * 16;        // GEMM 2 fragment: + ((8 kc + pc) * 64 + 16 pb) * 16
 
+    float sat_mx = 0.f;                                         // largest value handed to the fp16 split (post-clamp: == H2_MAX iff clamped)
     uint2 res[4][4][2];
     fetch_m(k0);
     load_res(k0, res);
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
                     const float y = fmaf(acc[gi][pb][e], s3[gi][e], b3[gi][e]);
                     v[e] = (e & 1) ? add_pieces_relu<1>(y, wh, wl, H2_MAX) : add_pieces_relu<0>(y, wh, wl, H2_MAX);
                 }
+                sat_track(sat_mx, v[0], v[1]);
+                sat_track(sat_mx, v[2], v[3]);
                 unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
                 unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
                 char* tl = sBuf + X::OFF_T + ((2 * (2 * g + (q >> 1))) * X::N + 16 * pb + px) * 16 + (q & 1) * 8;
@@ -190,6 +193,8 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = h2_sat(fmaxf(fmaf(acc2[pb][e], s1[e], b1[e]), 0.f));
+            sat_track(sat_mx, v[0], v[1]);
+            sat_track(sat_mx, v[2], v[3]);
             unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
             unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
             const u32x2_t a = __builtin_amdgcn_permlane16_swap(hh[0], hl[0], false, false);
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next m has landed (and everything else: a full drain per tile)
         __builtin_amdgcn_s_barrier();                          // t may be overwritten
     }
+    sat_report(p.sat, sat_mx);
 }
 
 // `opa`: the 64 -> 256 conv (+ residual + ReLU), `opb`: the 256 -> 64 conv (+ ReLU) reading its output
@@ -206,7 +212,8 @@ int launch_seam1x1(const romp_op& opa, const romp_op& opb, const float* m, const
     ROMP_REQUIRE(opa.ksize == 1 && opa.stride == 1 && opa.Cin == 64 && opa.Cout == 256 && opa.groups == 1 && opa.relu &&
                  opb.ksize == 1 && opb.stride == 1 && opb.Cin == 256 && opb.Cout == 64 && opb.groups == 1 && opb.relu,
                  "seam1x1: a 1x1 64 -> 256 conv + residual + ReLU followed by a 1x1 256 -> 64 conv + ReLU expected");
-    ROMP_REQUIRE(opa.weight_aux && opa.scale_h2 && opb.weight_aux && opb.scale_h2, "seam1x1: per-group f16x2 weight packs expected");
+    ROMP_REQUIRE(opa.weight_aux && opa.scale_h2 && opb.weight_aux && opb.scale_h2 && (opa.flags & opb.flags & ROMP_OPF_WAVE16),
+                 "seam1x1: per-group f16x2 weight packs (ROMP_OPF_WAVE16) expected");
     ROMP_REQUIRE(opa.in_fmt == ROMP_FMT_H2 && opa.res_fmt == ROMP_FMT_H2 && opa.out_fmt == ROMP_FMT_H2 && opb.in_fmt == ROMP_FMT_H2 &&
                  opb.out_fmt == ROMP_FMT_H2 && opa.act_shift == opb.act_shift, "seam1x1: H2 tensors expected");
     ROMP_REQUIRE(((long)B * opa.H * opa.W) % XCfg::N == 0 && opa.H == opb.H && opa.W == opb.W, "seam1x1: pixel count not a multiple of 64");
@@ -232,6 +239,7 @@ int launch_seam1x1(const romp_op& opa, const romp_op& opb, const float* m, const
     p.scale = opa.scale_h2; p.w = opa.shift;
     p.scale_h = opb.scale_h2; p.shift = opb.shift;
     p.act_scale = ldexpf(1.f, opa.act_shift);
+    p.sat = conv_sat_counter();
     {
         const unsigned long long bytes = ((unsigned long long)B * opa.H * opa.W * opa.in_cstride - opa.in_coff) * 4ull;
         ROMP_REQUIRE(bytes < 0x80000000ull, "seam1x1: input tensor of %llu bytes: beyond the 31-bit offsets of the DMA", bytes);

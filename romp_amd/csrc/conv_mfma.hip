@@ -29,7 +29,7 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
         float v = fmaf(acc, p.scale[g * p.cout_pad + co], p.shift[g * p.cout_pad + co]);
         const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox;
         if (p.res) v += p.res[pix * p.res_cs + p.res_co + g * p.res_gs + co];
-        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu && co >= p.relu_from) v = fmaxf(v, 0.f);
         p.out[(size_t)b * p.out_bs + (size_t)oy * p.out_rs + (size_t)ox * p.out_cs + p.out_co + g * p.out_gs + co] = v;
     }
 }
@@ -55,6 +55,8 @@ static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers wit
 static int* g_cu_slots = nullptr;           // ROMP_CONV_SKEW experiment: per-CU arrival counters
 static int g_skew = 0;
 static float* g_zero = nullptr;             // 256 bytes of zeros (out-of-image lanes of LDS-DMA pixel fetches)
+static int* g_sat = nullptr;                // saturation counter of the net being run (conv_set_sat_counter), or nullptr
+static bool g_sat_checked = false;          // run the counting builds of the fused-block kernels (romp_net_range_scan, ROMP_CHECK_FINITE=1)
 static unsigned long long* g_trace = nullptr;   // env ROMP_CONV_TRACE=1: per-wave phase stamps of the most recent split-precision conv launch
 
 static const int kMaxLds = 160 * 1024;
@@ -87,6 +89,11 @@ static int ensure_attrs() {
     g_attr_done = true;
     return ROMP_OK;
 }
+
+// The executor (net.hip) names the running net's counter before it enqueues; every launcher copies it into its parameters.
+void conv_set_sat_counter(int* counter, bool checked_fused) { g_sat = counter; g_sat_checked = checked_fused; }
+int* conv_sat_counter() { return g_sat; }
+bool conv_sat_checked() { return g_sat_checked; }
 
 // One-time per-process setup (LDS attributes, occupancy, scratch queue).  romp_net_create calls it so
 // that it never runs inside a stream capture (hipMalloc / hipFuncSetAttribute are illegal there).
@@ -178,6 +185,9 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.out_cs = op.out_cstride; p.out_co = op.out_coff; p.out_gs = op.out_gstride;
     p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.res_gs = op.res_gstride;
     p.relu = op.relu;
+    p.relu_from = op.relu ? op.relu_from : 0;
+    ROMP_REQUIRE(p.relu_from >= 0 && (p.relu_from & 31) == 0, "conv: relu_from %d must be a multiple of 32", op.relu_from);
+    p.sat = g_sat;
     p.w_gs = (op.ksize == 13 ? 3 : op.ksize * op.ksize) * op.cin_pad * op.cout_pad;
     const int kh = op.ksize == 13 ? 1 : op.ksize, kw = op.ksize == 13 ? 3 : op.ksize;
     p.pad_h = op.pad_h >= 0 ? op.pad_h : kh / 2;

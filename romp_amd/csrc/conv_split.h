@@ -152,9 +152,13 @@ __device__ __forceinline__ constexpr int frag_lane(int lh) { return NP == 2 ? lh
 
 // staging registers of one float4 of float32 activations (channels 4*qq .. 4*qq+3 of the chunk) -> NP pieces in LDS
 template <int NP, int CK>
-__device__ __forceinline__ void write_pieces(char* pix, int qq, float4 av, float act_scale) {
+__device__ __forceinline__ void write_pieces(char* pix, int qq, float4 av, float act_scale, float& sat_mx) {
     unsigned short h[4][NP];
-    if (NP == 2) { av.x *= act_scale; av.y *= act_scale; av.z *= act_scale; av.w *= act_scale; }
+    if (NP == 2) {
+        av.x *= act_scale; av.y *= act_scale; av.z *= act_scale; av.w *= act_scale;
+        sat_track(sat_mx, av.x, av.y);                         // Piece<2>::split clamps at +-65504: keep that observable (conv_common.h)
+        sat_track(sat_mx, av.z, av.w);
+    }
     Piece<NP>::split(av.x, h[0]);
     Piece<NP>::split(av.y, h[1]);
     Piece<NP>::split(av.z, h[2]);
@@ -240,6 +244,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
     unsigned ra_ok = 0;
     uint4 rb[X::NB];
     float rs = 0.f;
+    float sat_in = 0.f;                                // max |x * 2^act_shift| of the float32 pixels split while staged (f16x2, float32 input)
 
     auto issue_loads = [&](const Item& it, int c0) {
         const float* in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs;
@@ -291,7 +296,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
                 const float4 av = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                 char* pixp = sA + (pix / C::HC) * X::ROWB + (pix % C::HC) * X::PSB;
                 if (NP == 2 && p.in_h2) *reinterpret_cast<float4*>(pixp + qq * 16) = av;       // already split: a plain copy
-                else write_pieces<NP, CK>(pixp, qq, av, p.act_scale);
+                else write_pieces<NP, CK>(pixp, qq, av, p.act_scale, sat_in);
             }
         }
 #pragma unroll
@@ -366,6 +371,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
                 if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
                 ROMP_TRACE(14);                        // epilogue issued
             }
+            if (NP == 2 && !p.in_h2) { sat_report(p.sat, sat_in); sat_in = 0.f; }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -387,6 +393,7 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
             ++ch;
         }
     }
+    if (NP == 2 && !p.in_h2) sat_report(p.sat, sat_in);        // (the paths that leave the loop before the per-item report)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,6 +443,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
     float4 ra[C::NA];
     unsigned ra_ok = 0;
     float rs = 0.f;
+    float sat_in = 0.f;                                // (see conv_split_body)
 
     // LDS-DMA of the weight units of tap row `row`, channel chunk c0, into buffer `buf`
     auto issue_B = [&](const Item& it, int c0, int row, int buf) {
@@ -486,7 +494,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
                 const float4 av = ((ra_ok >> k) & 1u) ? ra[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                 char* pixp = sA + (pix / C::HC) * X::ROWB + (pix % C::HC) * X::PSB;
                 if (NP == 2 && p.in_h2) *reinterpret_cast<float4*>(pixp + qq * 16) = av;       // already split: a plain copy
-                else write_pieces<NP, CK>(pixp, qq, av, p.act_scale);
+                else write_pieces<NP, CK>(pixp, qq, av, p.act_scale, sat_in);
             }
         }
         if (first_chunk && tid < 2 * C::NW) sS[slot * 2 * C::NW + tid] = rs;
@@ -593,6 +601,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
                     if (!(p.dbg & 4)) conv_epilogue<KS, S, MT, NT, TW, CK>(p, cur, acc, sS + slot * 2 * C::NW, sE, wave, li, lh);
                     ROMP_TRACE(14);
                 }
+                if (NP == 2 && !p.in_h2) { sat_report(p.sat, sat_in); sat_in = 0.f; }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -619,6 +628,7 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
             ++row;
         }
     }
+    if (NP == 2 && !p.in_h2) sat_report(p.sat, sat_in);
 }
 
 }  // namespace romp

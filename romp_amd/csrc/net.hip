@@ -42,6 +42,8 @@ struct romp_net {
     std::vector<int64_t> buf_floats;     // per image
     std::vector<float*> bufs;
     int* queues = nullptr;               // 2 lanes x n_ops x QUEUE_INTS work counters, zeroed at the start of a forward
+    int* sat = nullptr;                  // saturation counter (conv_common.h sat_report): cumulative since create / the last reset
+    bool sat_checked = false;            // also launch the counting builds of the fused-block kernels (env ROMP_CHECK_FINITE=1, range scan)
     int max_batch = 0;
     int mode = 0;
     int use_graph = 0;
@@ -154,6 +156,8 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             for (int k = 0; k < op.n_terms; ++k) {
                 t[k].ptr = resolve_in(n, op.term_buf[k], image);
                 ROMP_REQUIRE(t[k].ptr, "fusesum: bad term buffer %d", op.term_buf[k]);
+                ROMP_REQUIRE(op.term_coff[k] >= 0 && (op.term_coff[k] & 7) == 0, "fusesum: term channel offset %d must be a multiple of 8", op.term_coff[k]);
+                t[k].ptr += op.term_coff[k];
                 t[k].shift = op.term_shift[k];
                 t[k].cstride = op.term_cstride[k];
                 t[k].fmt = op.term_fmt[k];
@@ -258,6 +262,7 @@ static int run_lane(romp_net* n, const float* image, int B, float* center, float
 static bool lanes_active(const romp_net* n, int B) { return n->split == 2 && n->mode == 0 && B >= 2 && !(B & 1); }
 
 static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st, size_t first_op = 0) {
+    conv_set_sat_counter(n->sat, n->sat_checked);
     int rc = reset_queues(n, st);
     if (rc) return rc;
     if (!lanes_active(n, B)) {
@@ -290,6 +295,16 @@ const char* romp_last_error(void) { return romp::g_err; }
 int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const int64_t* buf_floats, int n_bufs,
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
+    {   // One device per process (the design: one process per GPU, torch.distributed over RCCL): the launchers cache their one-time
+        // set-up -- raised dynamic-LDS limits, CU count, zero pages, occupancy -- per PROCESS.  A second net on another device would
+        // silently run with the first device's, so it is refused here.
+        static int g_device = -1;
+        int dev = -1;
+        ROMP_HIP_CHECK(hipGetDevice(&dev));
+        if (g_device < 0) g_device = dev;
+        ROMP_REQUIRE(dev == g_device, "romp_net_create: this process already runs nets on device %d; libromp_hip.so serves ONE device per "
+                     "process (launch one process per GPU), current device is %d", g_device, dev);
+    }
     { const int rc = conv_init(); if (rc) return rc; }
     for (int i = 1; i < n_ops; ++i)
         if (ops_host[i].kind == ROMP_OP_SEAM1X1) {
@@ -335,11 +350,13 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
         e = hipMemset(n->bufs[i], 0, bytes);
         if (e != hipSuccess) { set_error("hipMemset failed: %s", hipGetErrorString(e)); romp_net_destroy(n); return ROMP_EHIP; }
     }
-    if (hipMalloc((void**)&n->queues, (size_t)2 * n_ops * QUEUE_INTS * sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&n->queues, (size_t)2 * n_ops * QUEUE_INTS * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&n->sat, 64) != hipSuccess || hipMemset(n->sat, 0, 64) != hipSuccess) {
         set_error("queue allocation failed");
         romp_net_destroy(n);
         return ROMP_ENOMEM;
     }
+    { const char* e = getenv("ROMP_CHECK_FINITE"); n->sat_checked = e && e[0] && strcmp(e, "0") != 0; }
     bool ok = hipStreamCreateWithFlags(&n->lane_main, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&n->ev_begin, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&n->ev_offset, hipEventDisableTiming) == hipSuccess &&
@@ -392,6 +409,7 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     ROMP_REQUIRE(n && image && center && params && B > 0, "romp_net_forward: bad arguments");
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
+    conv_set_sat_counter(n->sat, n->sat_checked);
     if (!n->use_graph || n->mode != 0) return run_all(n, image, B, center, params, st);
     ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
     // The stem is the only op that reads the caller's image: launched eagerly in front of the graph, the graph no longer
@@ -458,6 +476,7 @@ int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
     ROMP_REQUIRE(n && B > 0 && iters > 0, "romp_net_autotune: bad arguments");
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
+    conv_set_sat_counter(nullptr, false);             // timing runs on whatever the arena holds: nothing to report
     std::vector<int> best(n->ops.size(), -1);
     // Scratch target for ops that read the caller's image or write the caller's output tensors: sized from the program
     // (largest per-image extent any conv touches through a pseudo buffer), not from one model's head.
@@ -520,6 +539,7 @@ int romp_net_profile(romp_net* n, const float* image, int B, float* center, floa
     ROMP_REQUIRE(n && image && center && params && ms_out && B > 0 && iters > 0, "romp_net_profile: bad arguments");
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
+    conv_set_sat_counter(n->sat, n->sat_checked);
     const size_t nops = n->ops.size();
     std::vector<hipEvent_t> ev(nops + 1);
     for (auto& e : ev) ROMP_HIP_CHECK(hipEventCreate(&e));
@@ -554,26 +574,33 @@ int romp_net_profile(romp_net* n, const float* image, int B, float* center, floa
 }
 
 // ---- activation range scan -----------------------------------------------------------------------------------------
-// max |x| and the number of non-finite values of a tensor region; H2 regions are decoded (h1 + h2) * 2^-shift per channel
-// octet (an octet = 32 bytes: eight high then eight low fp16 pieces).  One atomicMax on the float's bit pattern per wave.
-__global__ void range_scan_kernel(const float* x, size_t n, int h2, float inv_scale, unsigned* out_max, unsigned* out_bad) {
+// max |x| and the number of non-finite values of ONE op's output region: `C` channels at offset `coff` of every pixel (channel
+// stride `cs`) of B images `bstride` floats apart.  H2 regions are decoded (h1 + h2) * 2^-shift per channel octet (an octet = 32
+// bytes: eight high then eight low fp16 pieces).  One atomicMax on the float's bit pattern per wave.  (Round 3 reduced over the
+// whole arena buffer: stale data of earlier live ranges and neighbouring channel slices made the figure an upper bound that could
+// mask the too-small-for-fp16 test -- ADVICE r3.)
+struct ScanRegion { const float* x; int B; long long bstride; long long npix; int cs, coff, C, h2; float inv_scale; };
+__global__ void range_scan_kernel(ScanRegion r, unsigned* out_max, unsigned* out_bad) {
     float m = 0.f;
     unsigned bad = 0;
-    if (h2) {
-        const size_t n_oct = n >> 3;
-        for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n_oct; o += (size_t)gridDim.x * blockDim.x) {
-            const uint4 hi = *reinterpret_cast<const uint4*>(x + o * 8), lo = *reinterpret_cast<const uint4*>(x + o * 8 + 4);
-            const float4 a = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), inv_scale);
-            const float4 b = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), inv_scale);
-            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const int per_pix = r.h2 ? r.C >> 3 : r.C;                 // work units per pixel: octets / single channels
+    const size_t total = (size_t)r.B * r.npix * per_pix;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % per_pix);
+        const size_t pixb = i / per_pix;
+        const size_t pix = pixb % r.npix, b = pixb / r.npix;
+        const float* px = r.x + b * r.bstride + pix * r.cs + r.coff;
+        if (r.h2) {
+            const uint4 hi = *reinterpret_cast<const uint4*>(px + u * 8), lo = *reinterpret_cast<const uint4*>(px + u * 8 + 4);
+            const float4 a = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), r.inv_scale);
+            const float4 c = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), r.inv_scale);
+            const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (__builtin_isfinite(v[e])) m = fmaxf(m, fabsf(v[e])); else ++bad;
             }
-        }
-    } else {
-        for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-            const float v = x[i];
+        } else {
+            const float v = px[u];
             if (__builtin_isfinite(v)) m = fmaxf(m, fabsf(v)); else ++bad;
         }
     }
@@ -588,43 +615,101 @@ __global__ void range_scan_kernel(const float* x, size_t n, int h2, float inv_sc
     }
 }
 
+// the region an op writes into arena buffer op.out_buf: false for ops whose output is not a dense (pixels x channel slice) block
+// (sparse parity outputs of a transposed conv, the BEV head's 3-D tensors): those are scanned as whole buffers
+static bool op_out_region(const romp_op& op, long long* npix, int* cs, int* coff, int* C) {
+    int Ho = op.H, Wo = op.W;
+    switch (op.kind) {
+        case ROMP_OP_CONV: {
+            if (op.ksize == 13 || op.out_rstride > 0 || op.out_bstride > 0) return false;
+            const int k = op.ksize;
+            if (k == 2) { Ho = op.H / op.stride; Wo = op.W / op.stride; }
+            else { Ho = (op.H + 2 * (k / 2) - k) / op.stride + 1; Wo = (op.W + 2 * (k / 2) - k) / op.stride + 1; }
+            *C = op.groups > 1 ? (op.groups - 1) * op.out_gstride + op.Cout : op.Cout;
+            break; }
+        case ROMP_OP_STEM: case ROMP_OP_STEM7: Ho = op.H / 2; Wo = op.W / 2; *C = op.Cout; break;
+        case ROMP_OP_FUSESUM: case ROMP_OP_KSUM: case ROMP_OP_BBLOCK32: case ROMP_OP_BBLOCK64: case ROMP_OP_SEAM1X1: *C = op.Cout; break;
+        default: return false;
+    }
+    *npix = (long long)Ho * Wo; *cs = op.out_cstride; *coff = op.out_coff;
+    return *cs > 0 && *C > 0 && (op.out_fmt != ROMP_FMT_H2 || ((*C | *cs | *coff) & 7) == 0);
+}
+
 // Runs the program op by op (one stream, the variants of romp_net_autotune if it ran) and reports for every op that writes an
-// arena buffer the max |x| / non-finite count of that buffer's B images right after the op (a buffer shared by several live
-// ranges may still hold part of an older tensor: the figure is an upper bound).  plan.assign_formats uses it to keep tensors
-// whose range does not fit the fp16 pieces of the H2 format in float32 and their consumers on the f32 / bf16x3 kernels.
+// arena buffer the max |x| / non-finite count of the region it wrote (B images) right after the op, and how many saturation events
+// (conv_common.h sat_report: waves that clamped a value at +-65504 while splitting it into fp16 pieces) the op's kernels reported --
+// the fused-block kernels run their counting builds here.  plan.assign_formats uses max |x| (of a float32 lowering) to keep tensors
+// whose range does not fit the fp16 pieces of the H2 format in float32 and their consumers on the f32 / bf16x3 kernels; on the real
+// program the saturation column says which op clamped (RompNet.range_scan).
 int romp_net_range_scan(romp_net* n, const float* image, int B, float* center, float* params, void* stream,
-                        float* maxabs_out_host, int32_t* nonfinite_out_host) {
+                        float* maxabs_out_host, int32_t* nonfinite_out_host, int32_t* saturated_out_host) {
     ROMP_REQUIRE(n && image && center && params && maxabs_out_host && nonfinite_out_host && B > 0, "romp_net_range_scan: bad arguments");
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
     const size_t nops = n->ops.size();
-    unsigned* d = nullptr;
-    ROMP_HIP_CHECK(hipMalloc((void**)&d, 2 * nops * sizeof(unsigned)));
+    unsigned* d = nullptr;                                     // [max | bad | counter after op i] x nops
+    ROMP_HIP_CHECK(hipMalloc((void**)&d, 3 * nops * sizeof(unsigned)));
     int rc = ROMP_OK;
-    if (hipMemsetAsync(d, 0, 2 * nops * sizeof(unsigned), st) != hipSuccess) { set_error("hipMemsetAsync failed"); rc = ROMP_EHIP; }
+    if (hipMemsetAsync(d, 0, 3 * nops * sizeof(unsigned), st) != hipSuccess) { set_error("hipMemsetAsync failed"); rc = ROMP_EHIP; }
+    int sat_before = 0;
+    if (rc == ROMP_OK && (hipMemcpyAsync(&sat_before, n->sat, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        set_error("range scan: reading the saturation counter failed"); rc = ROMP_EHIP;
+    }
     const std::vector<int>* tv = tuned_for(n, B);
+    conv_set_sat_counter(n->sat, true);
     if (rc == ROMP_OK) rc = reset_queues(n, st);
     for (size_t i = 0; i < nops && rc == ROMP_OK; ++i) {
         rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, st);
         const romp_op& op = n->ops[i];
+        if (rc == ROMP_OK && hipMemcpyAsync(d + 2 * nops + i, n->sat, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("hipMemcpyAsync failed"); rc = ROMP_EHIP; }
         if (rc || op.out_buf < 0 || op.out_buf >= (int)n->bufs.size() || op.kind == ROMP_OP_FORK || op.kind == ROMP_OP_JOIN || op.kind == ROMP_OP_NOP) continue;
-        const size_t cnt = (size_t)n->buf_floats[op.out_buf] * B;
-        const int h2 = op.out_fmt == ROMP_FMT_H2;
-        hipLaunchKernelGGL(range_scan_kernel, dim3(1024), dim3(256), 0, st, n->bufs[op.out_buf], cnt, h2, ldexpf(1.f, -op.act_shift),
-                           d + i, d + nops + i);
+        ScanRegion r;
+        r.x = n->bufs[op.out_buf]; r.B = B; r.bstride = n->buf_floats[op.out_buf];
+        r.h2 = op.out_fmt == ROMP_FMT_H2; r.inv_scale = ldexpf(1.f, -op.act_shift);
+        if (!op_out_region(op, &r.npix, &r.cs, &r.coff, &r.C)) {      // the whole buffer as one "pixel" per 8 floats / per float
+            r.cs = r.h2 ? 8 : 1; r.coff = 0; r.C = r.cs; r.npix = r.bstride / r.cs;
+        }
+        hipLaunchKernelGGL(range_scan_kernel, dim3(1024), dim3(256), 0, st, r, d + i, d + nops + i);
         if (hipGetLastError() != hipSuccess) { set_error("range_scan_kernel launch failed"); rc = ROMP_EHIP; }
     }
-    std::vector<unsigned> h(2 * nops, 0u);
-    if (rc == ROMP_OK && hipMemcpyAsync(h.data(), d, 2 * nops * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("hipMemcpyAsync failed"); rc = ROMP_EHIP; }
+    conv_set_sat_counter(n->sat, n->sat_checked);
+    std::vector<unsigned> h(3 * nops, 0u);
+    if (rc == ROMP_OK && hipMemcpyAsync(h.data(), d, 3 * nops * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("hipMemcpyAsync failed"); rc = ROMP_EHIP; }
     if (hipStreamSynchronize(st) != hipSuccess && rc == ROMP_OK) { set_error("hipStreamSynchronize failed"); rc = ROMP_EHIP; }
     hipFree(d);
+    int prev = sat_before;
     for (size_t i = 0; i < nops; ++i) {
         float f;
         memcpy(&f, &h[i], sizeof(float));
         maxabs_out_host[i] = f;
         nonfinite_out_host[i] = (int32_t)h[nops + i];
+        const int now = (int)h[2 * nops + i];
+        if (saturated_out_host) saturated_out_host[i] = rc == ROMP_OK ? now - prev : 0;
+        prev = now;
     }
     return rc;
+}
+
+// The net's saturation counter: the number of (wave, work item) events since create / the last reset in which a kernel clamped a
+// value at +-65504 while splitting it into fp16 pieces of x * 2^act_shift -- an activation outside the calibrated range: the
+// result is finite but wrong there.  0 for a healthy net.  Synchronises `stream`.
+int romp_net_saturated(romp_net* n, int64_t* count_host, int reset, void* stream) {
+    ROMP_REQUIRE(n && count_host, "romp_net_saturated: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int v = 0;
+    ROMP_HIP_CHECK(hipMemcpyAsync(&v, n->sat, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (reset) ROMP_HIP_CHECK(hipMemsetAsync(n->sat, 0, sizeof(int), st));
+    ROMP_HIP_CHECK(hipStreamSynchronize(st));
+    *count_host = v;
+    return ROMP_OK;
+}
+
+// 1: the fused BasicBlock kernels run their counting builds too (a few percent slower; default: env ROMP_CHECK_FINITE=1).
+int romp_net_set_sat_check(romp_net* n, int enable) {
+    ROMP_REQUIRE(n, "romp_net_set_sat_check: null net");
+    n->sat_checked = enable != 0;
+    drop_graphs(n);
+    return ROMP_OK;
 }
 
 int romp_net_read_buffer(romp_net* n, int buf, int B, float* dst, int64_t n_floats, void* stream) {
@@ -649,6 +734,10 @@ void romp_net_destroy(romp_net* n) {
     for (float* p : n->bufs)
         if (p) hipFree(p);
     if (n->queues) hipFree(n->queues);
+    if (n->sat) {
+        if (conv_sat_counter() == n->sat) conv_set_sat_counter(nullptr, false);      // no launcher may keep a pointer into a dead net
+        hipFree(n->sat);
+    }
     if (n->plan_dev) hipFree(n->plan_dev);
     for (int l = 0; l < 2; ++l) {
         for (int k = 0; k < 3; ++k) {
@@ -667,6 +756,7 @@ void romp_net_destroy(romp_net* n) {
 int romp_conv_forward(const romp_op* op, const float* in, const float* res, float* out, int B, int mode, int variant,
                       void* stream) {
     ROMP_REQUIRE(op && in && out && B > 0, "romp_conv_forward: bad arguments");
+    conv_set_sat_counter(nullptr, false);              // a stand-alone layer belongs to no net: nothing to report to
     if (op->kind == ROMP_OP_STEM) return launch_stem(*op, in, out, B, (hipStream_t)stream);
     ROMP_REQUIRE(op->kind == ROMP_OP_CONV, "romp_conv_forward: op kind %d", op->kind);
     return launch_conv(*op, in, res, out, B, mode, variant, nullptr, (hipStream_t)stream);

@@ -18,6 +18,7 @@ struct StemParams {
     const float* image; const float* w; const float* scale; const float* shift; float* out;
     int H, W, Ho, Wo, out_cs, out_co, tiles_x, tiles_y;
     int out_h2; float act_scale;      // output in the H2 format (conv_common.h)
+    int* sat;                         // saturation counter (conv_common.h sat_report), or nullptr
 };
 
 // packed stem weight: [tap 9][cin 3][cout 64]
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     const float4 sc = *reinterpret_cast<const float4*>(p.scale + cg * 4);
     const float4 sh = *reinterpret_cast<const float4*>(p.shift + cg * 4);
     float* out = p.out + (size_t)b * p.Ho * p.Wo * p.out_cs + p.out_co;
+    float sat_mx = 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int oy = ty * T + wave * 4 + (t >> 2), ox = tx * T + (t & 3) * 4 + ps;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
             // pieces, odd lane: the eight low pieces): a wave's store covers 4 pixels x 256 contiguous bytes, instead of two
             // instructions of 8-byte pieces on alternating 16-byte slots (the 8-byte stores had this kernel at 2.2 TB/s)
             uint2 hi, lo;
-            h2_pack(v, p.act_scale, hi, lo);
+            h2_pack(v, p.act_scale, hi, lo, sat_mx);
             const bool odd = cg & 1;
             const uint2 send = odd ? hi : lo;
             uint2 recv;
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
             *reinterpret_cast<float4*>(out + ((size_t)oy * p.Wo + ox) * p.out_cs + cg * 4) = v;
         }
     }
+    if (p.out_h2) sat_report(p.sat, sat_mx);
 }
 
 // The same layer on the matrix cores (round 3, H2 output only): the VALU kernel above is instruction-bound (1 728 FMAs per thread,
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p) {
     // epilogue: lane (px, q) holds channels 16 g + 4 q .. + 3 of pixel px of row block r: BN + ReLU in the scaled domain, split, the
     // lanes of an octet trade halves (v_permlane16_swap) and each stores one 16-byte unit
     const float prod_scale = p.act_scale * (1.0f / 4096.0f);
+    float sat_mx = 0.f;
     float* out = p.out + (size_t)b * p.Ho * p.Wo * p.out_cs + p.out_co + ((size_t)(ty * T + 4 * wave) * p.Wo + tx * T + px) * p.out_cs + 4 * q;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -219,7 +223,11 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p) {
         for (int r = 0; r < 4; ++r) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = h2_sat(fmaxf(fmaf(acc[r][g][e], s4[e], b4[e]), 0.f));
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(acc[r][g][e], s4[e], b4[e]), 0.f);
+            sat_track(sat_mx, v[0], v[1]);
+            sat_track(sat_mx, v[2], v[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h2_sat(v[e]);
             unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
             unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
             const u32x2_t a = __builtin_amdgcn_permlane16_swap(hh[0], hl[0], false, false);
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p) {
             *reinterpret_cast<uint4*>(out + (size_t)r * p.Wo * p.out_cs + 16 * g) = make_uint4(a[0], c[0], a[1], c[1]);
         }
     }
+    sat_report(p.sat, sat_mx);
 }
 
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st) {
@@ -238,10 +247,13 @@ int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStr
     p.H = op.H; p.W = op.W; p.Ho = op.H / 2; p.Wo = op.W / 2;
     p.out_cs = op.out_cstride; p.out_co = op.out_coff;
     p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.act_scale = ldexpf(1.f, op.act_shift);
+    p.sat = conv_sat_counter();
     ROMP_REQUIRE(!p.out_h2 || ((op.out_cstride | op.out_coff) & 7) == 0, "stem: H2 output needs octet-aligned channels");
     p.tiles_x = p.Wo / 16; p.tiles_y = p.Ho / 16;
-    static int use_mfma = -1;                                  // env ROMP_STEM=valu: the VALU kernel for the H2 output too (A/B runs)
-    if (use_mfma < 0) { const char* e = getenv("ROMP_STEM"); use_mfma = (e && !strcmp(e, "valu")) ? 0 : 1; }
+    // ROMP_OPF_STEM_VALU (plan.Program.stem): the float32 VALU kernel for the H2 output too -- set by env ROMP_STEM=valu (A/B runs,
+    // tests) and whenever 256 |w| would leave the fp16 pieces of the MFMA form (its 16x input / 256x weight scales are internal to
+    // the kernel: x/255*2-1 lies in [-1, 1] whatever act_shift the OUTPUT tensor uses).
+    const bool use_mfma = !(op.flags & ROMP_OPF_STEM_VALU);
     if (p.out_h2 && use_mfma) hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)(B * p.tiles_x * p.tiles_y)), dim3(256), 0, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
@@ -377,13 +389,15 @@ int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStr
 }
 
 struct FuseParams {
-    const float* t[4]; int shift[4]; int cs[4]; int h2[4];
+    const float* t[4]; int shift[4]; int cs[4]; int h2[4];        // (a term's channel offset is folded into its pointer)
     float* out; int n_terms, H, W, C8, out_cs, out_co, relu, out_h2; float act_scale, inv_act_scale; size_t total;
+    int* sat;
 };
 
 // One thread per pixel and channel OCTET (32 bytes in either format).  H2 terms are summed in the scaled domain
 // (x * 2^act_shift: exact, a power of two commutes with every f32 rounding), float32 terms are scaled on the way in.
 __global__ __launch_bounds__(256) void fusesum_kernel(FuseParams p) {
+    float sat_mx = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.total; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
         const int c = (int)(r % p.C8) * 8; r /= p.C8;
@@ -423,8 +437,8 @@ __global__ __launch_bounds__(256) void fusesum_kernel(FuseParams p) {
         float* op_ = p.out + (((size_t)b * p.H + y) * p.W + x) * p.out_cs + p.out_co + c;
         if (p.out_h2) {
             uint2 ha, la, hb, lb;
-            h2_pack(va, 1.f, ha, la);
-            h2_pack(vb, 1.f, hb, lb);
+            h2_pack(va, 1.f, ha, la, sat_mx);
+            h2_pack(vb, 1.f, hb, lb, sat_mx);
             *reinterpret_cast<uint4*>(op_) = make_uint4(ha.x, ha.y, hb.x, hb.y);
             *reinterpret_cast<uint4*>(op_ + 4) = make_uint4(la.x, la.y, lb.x, lb.y);
         } else {
@@ -433,6 +447,7 @@ __global__ __launch_bounds__(256) void fusesum_kernel(FuseParams p) {
             *reinterpret_cast<float4*>(op_ + 4) = make_float4(vb.x * os, vb.y * os, vb.z * os, vb.w * os);
         }
     }
+    if (p.out_h2) sat_report(p.sat, sat_mx);
 }
 
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
@@ -452,6 +467,7 @@ int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H,
     p.out_h2 = out_fmt == ROMP_FMT_H2;
     ROMP_REQUIRE(!p.out_h2 || ((out_cstride | out_coff) & 7) == 0, "fusesum: H2 output needs octet-aligned channels");
     p.act_scale = ldexpf(1.f, act_shift); p.inv_act_scale = ldexpf(1.f, -act_shift);
+    p.sat = conv_sat_counter();
     p.total = (size_t)B * H * W * p.C8;
     size_t blocks = (p.total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -468,9 +484,11 @@ struct KsumParams {
     const float* part; const float* res; const float* scale; const float* shift; float* out;
     int G, C, C8, part_cs, res_cs, res_co, out_cs, out_co, relu, res_h2, out_h2;
     float act_scale, inv_act_scale; size_t total;
+    int* sat;
 };
 
 __global__ __launch_bounds__(256) void ksum_kernel(KsumParams p) {
+    float sat_mx = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % p.C8) * 8;
         const size_t pix = i / p.C8;
@@ -519,8 +537,8 @@ __global__ __launch_bounds__(256) void ksum_kernel(KsumParams p) {
         float* op_ = p.out + pix * p.out_cs + p.out_co + c;
         if (p.out_h2) {
             uint2 h0, l0, h1, l1;
-            h2_pack(va, p.act_scale, h0, l0);
-            h2_pack(vb, p.act_scale, h1, l1);
+            h2_pack(va, p.act_scale, h0, l0, sat_mx);
+            h2_pack(vb, p.act_scale, h1, l1, sat_mx);
             *reinterpret_cast<uint4*>(op_) = make_uint4(h0.x, h0.y, h1.x, h1.y);
             *reinterpret_cast<uint4*>(op_ + 4) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         } else {
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(256) void ksum_kernel(KsumParams p) {
             *reinterpret_cast<float4*>(op_ + 4) = vb;
         }
     }
+    if (p.out_h2) sat_report(p.sat, sat_mx);
 }
 
 int launch_ksum(const romp_op& op, const float* partial, const float* res, float* out, int B, hipStream_t st) {
@@ -540,6 +559,7 @@ int launch_ksum(const romp_op& op, const float* partial, const float* res, float
     p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.out_cs = op.out_cstride; p.out_co = op.out_coff; p.relu = op.relu;
     p.res_h2 = op.res_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2;
     p.act_scale = ldexpf(1.f, op.act_shift); p.inv_act_scale = ldexpf(1.f, -op.act_shift);
+    p.sat = conv_sat_counter();
     p.total = (size_t)B * op.H * op.W * p.C8;
     size_t blocks = (p.total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

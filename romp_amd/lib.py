@@ -10,12 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libromp_hip.so')
 
-ABI_VERSION = 4          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
+ABI_VERSION = 5          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
 FMT_F32, FMT_H2 = 0, 1
 OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN, OP_BEV_PACK, OP_BEV_MAPS, OP_CONV3D = 1, 2, 3, 4, 5, 6, 7, 8
 OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1 = 12, 13, 14, 15
 OP_KSUM = 11
+OPF_WAVE16, OPF_STEM_VALU = 1, 2
 
 
 class RompOp(C.Structure):
@@ -36,6 +37,7 @@ class RompOp(C.Structure):
         ('stream', C.c_int32), ('pad_h', C.c_int32), ('pad_w', C.c_int32), ('out_rstride', C.c_int32), ('out_bstride', C.c_int32),
         ('in_fmt', C.c_int32), ('out_fmt', C.c_int32), ('res_fmt', C.c_int32), ('term_fmt', C.c_int32 * 4),
         ('act_shift', C.c_int32),
+        ('flags', C.c_int32), ('relu_from', C.c_int32), ('term_coff', C.c_int32 * 4),
         ('weight', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p), ('weight_aux', C.c_void_p),
         ('weight_h2', C.c_void_p), ('scale_h2', C.c_void_p),
     ]
@@ -71,7 +73,9 @@ def load():
         'romp_net_set_graph': (C.c_int, [vp, i32]),
         'romp_net_set_streams': (C.c_int, [vp, i32]),
         'romp_net_profile': (C.c_int, [vp, vp, i32, vp, vp, vp, C.POINTER(C.c_float), i32]),
-        'romp_net_range_scan': (C.c_int, [vp, vp, i32, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+        'romp_net_range_scan': (C.c_int, [vp, vp, i32, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        'romp_net_saturated': (C.c_int, [vp, C.POINTER(C.c_int64), i32, vp]),
+        'romp_net_set_sat_check': (C.c_int, [vp, i32]),
         'romp_net_destroy': (None, [vp]),
         'romp_conv_forward': (C.c_int, [C.POINTER(RompOp), vp, vp, vp, i32, i32, i32, vp]),
         'romp_conv_num_variants': (C.c_int, []),
@@ -117,7 +121,7 @@ def load():
 
 
 EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_forward', 'romp_net_read_buffer',
-           'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_set_streams', 'romp_net_profile', 'romp_net_range_scan', 'romp_net_destroy',
+           'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_set_streams', 'romp_net_profile', 'romp_net_range_scan', 'romp_net_saturated', 'romp_net_set_sat_check', 'romp_net_destroy',
            'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_trace_read', 'romp_conv_describe',
            'romp_net_load', 'romp_net_plan_info', 'romp_net_autotune', 'romp_net_tuned_variant', 'romp_net_set_tuned', 'romp_net_set_split', 'romp_project_verts', 'romp_estimate_translation', 'romp_cam_to_trans', 'romp_bev_project_verts', 'romp_oneeuro_state_floats', 'romp_oneeuro_smooth', 'romp_sim3dr_normals', 'romp_sim3dr_light', 'romp_sim3dr_rasterize', 'romp_bev_workspace_ints', 'romp_bev_parse', 'romp_bev_regress',
            'romp_net_buffer_ptr', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',

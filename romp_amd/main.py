@@ -61,6 +61,11 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--plan_path', type=str, default=None,
                         help='[romp_amd] start from a plan file (python -m romp_amd.export: the lowered network with its packed constants '
                              'and measured kernel tables) instead of --model_path: the counterpart of the reference\'s --onnx / --model_onnx_path')
+    parser.add_argument('--no_calibrate', action='store_true',
+                        help='[romp_amd] skip the start-up range calibration of the f16x2 kernels (one float32 forward; tensors whose range does '
+                             'not fit fp16 pieces stay float32): ranges are then trusted, out-of-range values saturate (RompNet.saturated counts them)')
+    parser.add_argument('--calib_dir', type=str, default=None,
+                        help='[romp_amd] calibrate on up to 4 images of this directory (pre-processed like inputs) instead of synthetic frames')
     parser.add_argument('--host_preprocess', action='store_true', help='[romp_amd] pad/resize on the host (cv2 / numpy) instead of the device kernel')
     args = parser.parse_args(input_args)
     if not torch.cuda.is_available():
@@ -105,7 +110,25 @@ class ROMP(nn.Module):
         if getattr(self.settings, 'backbone', 'hrnet32') == 'resnet50':
             from .resnet_plan import build_romp_resnet50 as builder
         self.model = RompNet(state_dict, self.tdevice, max_batch=getattr(self.settings, 'max_batch', 32), builder=builder,
-                             bf16x3=getattr(self.settings, 'conv_math', 'f16x2'))
+                             bf16x3=getattr(self.settings, 'conv_math', 'f16x2'),
+                             calibrate=False if getattr(self.settings, 'no_calibrate', False) else None,
+                             calib_images=self._calibration_frames())
+
+    def _calibration_frames(self):
+        """--calib_dir: up to 4 real frames, pre-processed exactly like inputs, for RompNet's range calibration (the
+        synthetic default frames are not photos).  None: the synthetic set."""
+        d = getattr(self.settings, 'calib_dir', None)
+        if not d:
+            return None
+        paths = sorted(osp.join(d, f) for f in os.listdir(d) if f.lower().endswith(('.jpg', '.jpeg', '.png', '.bmp'))) if osp.isdir(d) else [d]
+        frames = []
+        for path in paths[:4]:
+            img = _imread_bgr(path)
+            if img is not None:
+                frames.append(img_preprocess_device(img, self.tdevice)[0])
+        if not frames:
+            raise L.RompHipError('--calib_dir %s holds no readable image' % d)
+        return torch.cat(frames, 0)
 
     def _initilization_(self, smpl_model=None):
         self.centermap_parser = CenterMap(conf_thresh=self.settings.center_thresh)
@@ -314,18 +337,26 @@ class ROMP(nn.Module):
         cur.wait_stream(P['stream'])
 
 
+def _imread_bgr(path):
+    """cv2.imread(path) (BGR uint8), or the same array through PIL when OpenCV is not installed; None if unreadable."""
+    try:
+        import cv2
+        return cv2.imread(path)
+    except ImportError:
+        from PIL import Image
+        try:
+            return np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1])
+        except OSError:
+            return None
+
+
 def main():
     """main.py:178-204 (image mode; video/webcam need OpenCV)."""
     args = romp_settings()
     romp = ROMP(args)
     if args.mode == 'image':
         saver = ResultSaver(args.mode, args.save_path)
-        try:
-            import cv2
-            image = cv2.imread(args.input)
-        except ImportError:
-            from PIL import Image
-            image = np.asarray(Image.open(args.input).convert('RGB'))[:, :, ::-1]
+        image = _imread_bgr(args.input)
         outputs = romp(image)
         saver(outputs, args.input)
     else:

@@ -19,7 +19,7 @@ _CHECK_FINITE = os.environ.get('ROMP_CHECK_FINITE', '0') not in ('', '0')
 
 class RompNet:
     def __init__(self, state_dict, device='cuda:0', max_batch=32, input_size=512, use_graph=False, builder=None,
-                 out_shapes=None, bf16x3=False, split_k=None, calibrate=None, calib_images=None):
+                 out_shapes=None, bf16x3=False, split_k=None, calibrate=None, calib_images=None, calib_margin=None):
         """`builder(state_dict, device, input_size, bf16x3=) -> Program` (default: ROMP HRNet-32 + head);
         `out_shapes`: per-image shapes of the two output tensors of the program.  `bf16x3` is the conv_math
         setting: False / 'f32', True / 'bf16x3', 'f16x2' or 'all' (plan.set_conv_math).  `split_k`: lower the layers with few
@@ -28,7 +28,11 @@ class RompNet:
         work-item target (default 128).  `calibrate` (default: whenever the f16x2 kernels are on offer): measure every
         tensor's max|x| with a float32 forward of `calib_images` ((B,S,S,3) float 0..255 on the device; default: synthetic
         frames) and keep tensors / layers whose range does not fit the fp16 pieces on the float32 path (plan.assign_formats,
-        `self.range_fallback` lists them); False skips it (ranges are then trusted to fit, the kernels only saturate)."""
+        `self.range_fallback` lists them); False skips it (ranges are then trusted to fit, the kernels only saturate).
+        `calib_margin`: head-room factor between the largest calibrated value of a tensor and the fp16 limit (default
+        plan.CALIB_MARGIN = 4; the synthetic default frames are not photos -- pass real frames through `calib_images`, e.g.
+        ROMP(--calib_dir), for a production checkpoint).  What calibration cannot foresee stays OBSERVABLE: `self.saturated`
+        counts the clamps the kernels report (0 for a healthy net), `range_scan(images)` says which op clamped."""
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise L.RompHipError('RompNet needs a HIP device (the HIP path has no CPU fallback)')
@@ -52,6 +56,8 @@ class RompNet:
                 self.op_maxabs = self._measure_ranges(state_dict, builder, kw, input_size, out_shapes or ((ms, ms), (ms, ms, 145)),
                                                       calib_images)
                 self.program.op_maxabs = self.op_maxabs
+                if calib_margin is not None:
+                    self.program.calib_margin = float(calib_margin)
             ops = self.program.op_array()
             self.range_fallback = list(getattr(self.program, 'range_fallback', []))
             sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
@@ -101,7 +107,7 @@ class RompNet:
             q = torch.empty((B,) + tuple(out_shapes[1]), device=self.device)
             mx = (C.c_float * len(P32.ops))()
             bad = (C.c_int32 * len(P32.ops))()
-            L.check(self.lib.romp_net_range_scan(h, L.ptr(calib_images[:B]), B, L.ptr(c), L.ptr(q), L.stream_ptr(self.device), mx, bad))
+            L.check(self.lib.romp_net_range_scan(h, L.ptr(calib_images[:B]), B, L.ptr(c), L.ptr(q), L.stream_ptr(self.device), mx, bad, None))
         finally:
             self.lib.romp_net_destroy(h)
         out = []
@@ -190,7 +196,47 @@ class RompNet:
             if not (bool(torch.isfinite(center_out).all()) and bool(torch.isfinite(params_out).all())):
                 raise L.RompHipError('non-finite values in the network outputs (activation range outside the f16x2 kernels\' '
                                      'fp16 pieces? build the net with calibrate=True / conv_math=\'f32\')')
+            n_sat = self.saturated                            # (the fused-block kernels run their counting builds in this mode)
+            if n_sat and not getattr(self, '_sat_warned', False):
+                import warnings
+                self._sat_warned = True
+                warnings.warn('RompNet: %d saturation events -- activations beyond the calibrated range of the f16x2 kernels were '
+                              'clamped at 65504 / 2^act_shift (finite but wrong there); calibrate on representative frames '
+                              '(calib_images= / --calib_dir) or use conv_math=\'f32\'; range_scan(images) names the ops' % n_sat)
         return center_out, params_out
+
+    @property
+    def saturated(self):
+        """Saturation events since the net was built (or `reset_saturated()`): how many (wave, work item) times a kernel clamped a
+        value at +-65504 while splitting it into the fp16 pieces of the H2 format -- 0 for a net inside its calibrated range.
+        Synchronises the current stream.  The two register-resident fused BasicBlock kernels count only under
+        ROMP_CHECK_FINITE=1 / `set_sat_check(True)` and in `range_scan`."""
+        v = C.c_int64(0)
+        L.check(self.lib.romp_net_saturated(self._h, C.byref(v), 0, L.stream_ptr(self.device)))
+        return int(v.value)
+
+    def reset_saturated(self):
+        v = C.c_int64(0)
+        L.check(self.lib.romp_net_saturated(self._h, C.byref(v), 1, L.stream_ptr(self.device)))
+        return int(v.value)
+
+    def set_sat_check(self, enable):
+        """Run the counting builds of the fused BasicBlock kernels too (a little slower; the default follows ROMP_CHECK_FINITE)."""
+        L.check(self.lib.romp_net_set_sat_check(self._h, int(bool(enable))))
+
+    def range_scan(self, image):
+        """Diagnosis on THIS net's program (not the float32 lowering calibration uses): runs it op by op on `image` and returns
+        per op (name, max|x| of the region it wrote, non-finite count, saturation events it reported)."""
+        B = image.shape[0]
+        Bt = B // 2 if (self.split == 2 and B >= 2 and B % 2 == 0) else B
+        if self.bf16x3 and Bt not in self._tuned:
+            self.autotune(Bt)
+        c = torch.empty((B,) + tuple(self.out_shapes[0]), device=self.device)
+        q = torch.empty((B,) + tuple(self.out_shapes[1]), device=self.device)
+        n = len(self.program.ops)
+        mx, bad, sat = (C.c_float * n)(), (C.c_int32 * n)(), (C.c_int32 * n)()
+        L.check(self.lib.romp_net_range_scan(self._h, L.ptr(image.contiguous()), B, L.ptr(c), L.ptr(q), L.stream_ptr(self.device), mx, bad, sat))
+        return [(self.program.names[i], float(mx[i]), int(bad[i]), int(sat[i])) for i in range(n)]
 
     def __call__(self, image):
         """Reference layout: center_maps (B,1,64,64), params_maps (B,145,64,64) (views, no copy)."""

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OPF_WAVE16, OPF_STEM_VALU, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -118,17 +118,20 @@ def pack_conv_weight_h2(w, cin_pad, cout_pad):
 
 ACT_SHIFT = 4            # f16x2 kernels: activations are split as fp16 pieces of 16*x (|x| < 4094)
 # Range of max|x| over a tensor for which the fp16 pieces of x * 2^ACT_SHIFT are as good as float32 (DESIGN.md section 4,
-# "range safety"): above H2_HI the high piece would leave fp16 (the kernels saturate at 65504 = 4094 * 16; the limit keeps a
-# factor two of head-room over the calibration data), below H2_LO most high pieces are fp16 subnormals and the pair holds fewer
-# than 22 bits relative to the tensor's largest values.  assign_formats keeps tensors outside it in float32 and takes the f16x2
-# weights away from their consumers (they run on the f32 / bf16x3 kernels).
-H2_HI = 2.0 ** (15 - ACT_SHIFT)
+# "range safety"): the high piece leaves fp16 at 65504 = 4094 * 16 (the kernels saturate there); H2_HI keeps a factor CALIB_MARGIN
+# of head-room over the CALIBRATION data (round 3: 2; round 4: 4 -- the default calibration frames are synthetic, and what still
+# escapes is counted: RompNet.saturated); below H2_LO most high pieces are fp16 subnormals and the pair holds fewer than 22 bits
+# relative to the tensor's largest values.  assign_formats keeps tensors outside it in float32 and takes the f16x2 weights away
+# from their consumers (they run on the f32 / bf16x3 kernels).
+CALIB_MARGIN = 4.0
+H2_HI = 2.0 ** (16 - ACT_SHIFT) / CALIB_MARGIN
 H2_LO = 2.0 ** (-2 - ACT_SHIFT)
 
 
-def h2_range_ok(maxabs):
-    """May a tensor whose largest magnitude is `maxabs` (None: not measured) be split into fp16 pieces of x * 2^ACT_SHIFT?"""
-    return maxabs is None or maxabs == 0.0 or (H2_LO <= maxabs < H2_HI)
+def h2_range_ok(maxabs, margin=CALIB_MARGIN):
+    """May a tensor whose largest calibrated magnitude is `maxabs` (None: not measured) be split into fp16 pieces of
+    x * 2^ACT_SHIFT, with a factor `margin` of head-room below the fp16 limit?"""
+    return maxabs is None or maxabs == 0.0 or (H2_LO <= maxabs < 2.0 ** (16 - ACT_SHIFT) / margin)
 
 
 def set_conv_math(P, conv_math):
@@ -244,7 +247,7 @@ def assign_formats(P):
             if not any(r == 'out' for _, r in g['uses']):    # initialised from outside the program: the host may state its range
                 ms = [v for v in [getattr(P, 'buf_maxabs', {}).get(g['buf'])] if v is not None]
             m = max(ms) if ms else None
-            if not h2_range_ok(m):
+            if not h2_range_ok(m, getattr(P, 'calib_margin', CALIB_MARGIN)):
                 g['ok'] = False
                 for i, r in g['uses']:
                     if r == 'in' and P.ops[i].kind == OP_CONV and P.ops[i].weight_h2:
@@ -308,6 +311,7 @@ def fuse_bottleneck_seams(P):
             t = pack_h2_wave16(by_ptr[o.weight_h2].view(*shape))
             P.consts.append(t)
             o.weight_aux = t.data_ptr()
+            o.flags |= OPF_WAVE16
         a.kind, b.kind = OP_NOP, OP_SEAM1X1
         P.flops[i + 1] += P.flops[i]
         P.flops[i] = 0.0
@@ -358,12 +362,14 @@ def fuse_basic_blocks(P):
         if plain and chained and h2 and private and a.act_shift == b.act_shift:
             # the row-pipelined kernels (conv_h2c.hip) read their weights per wave (16 output channels each).  32 channels: batch plans only
             # (two workgroups per CU; a single image's tiles are better off on conv_h2b.hip's kernel: 2.10 vs 2.15 ms at B = 1)
-            if C_ == 64 or (os.environ.get('ROMP_BBLOCK32', 'r') == 'r' and not getattr(P, 'split_k_items', 0)):
+            # ROMP_BBLOCK32=v1: conv_h2b.hip's kernel everywhere (A/B runs); anything else: the default
+            if C_ == 64 or (os.environ.get('ROMP_BBLOCK32', 'r') != 'v1' and not getattr(P, 'split_k_items', 0)):
                 by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
                 for o in (a, b):
                     t = pack_h2_wave16(by_ptr[o.weight_h2].view(9, C_ // 16, 2, 2, C_, 8))
                     P.consts.append(t)
-                    o.weight_aux = t.data_ptr()
+                    o.weight_aux = t.data_ptr()          # (replaces the bf16x3 pack of conv_math='all': a fused op runs no bf16x3 kernel)
+                    o.flags |= OPF_WAVE16                # the dispatch flag of launch_bblock32 / 64: never weight_aux != NULL alone
             a.kind, b.kind = OP_NOP, (OP_BBLOCK32 if C_ == 32 else OP_BBLOCK64)
             P.flops[i + 1] += P.flops[i]
             P.flops[i] = 0.0
@@ -577,6 +583,12 @@ class Program:
         op.H, op.W, op.Cin, op.Cout, op.ksize, op.stride, op.relu, op.groups = H, W, 3, 64, 3, 2, 1, 1
         op.in_cstride, op.out_cstride = 3, 64
         op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+        # stem_mfma_kernel splits 256 w into fp16 pieces: a weight beyond +-255.9 would be clamped -> the exact float32
+        # VALU kernel for such a checkpoint; env ROMP_STEM=valu forces it (A/B runs)
+        import os
+        wmax = float(w.abs().max()) if w.numel() else 0.0
+        if os.environ.get('ROMP_STEM', '') == 'valu' or not (wmax * 256.0 < 65504.0):
+            op.flags |= OPF_STEM_VALU
         self.ops.append(op)
         self.names.append(name)
         self.flops.append(2.0 * (H // 2) * (W // 2) * 64 * 27)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), 'libromp_hip.so does not export %s' % n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert h.romp_abi_version() == L.ABI_VERSION == 4
+    assert h.romp_abi_version() == L.ABI_VERSION == 5
 
 
 def test_romp_op_struct_layout_matches_header():
@@ -38,9 +38,9 @@ def test_romp_op_struct_layout_matches_header():
     #include <stdio.h>
     #include <stddef.h>
     #include "romp_hip.h"
-    int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(romp_op), offsetof(romp_op, groups),
+    int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(romp_op), offsetof(romp_op, groups),
         offsetof(romp_op, term_buf), offsetof(romp_op, weight), offsetof(romp_op, shift), offsetof(romp_op, act_shift),
-        offsetof(romp_op, scale_h2)); return 0; }
+        offsetof(romp_op, scale_h2), offsetof(romp_op, flags), offsetof(romp_op, relu_from), offsetof(romp_op, term_coff)); return 0; }
     '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, 't.c')
@@ -49,7 +49,33 @@ def test_romp_op_struct_layout_matches_header():
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
         vals = [int(v) for v in subprocess.check_output([exe]).split()]
     assert vals == [C.sizeof(RompOp), RompOp.groups.offset, RompOp.term_buf.offset, RompOp.weight.offset,
-                    RompOp.shift.offset, RompOp.act_shift.offset, RompOp.scale_h2.offset]
+                    RompOp.shift.offset, RompOp.act_shift.offset, RompOp.scale_h2.offset, RompOp.flags.offset,
+                    RompOp.relu_from.offset, RompOp.term_coff.offset]
+
+
+def test_fused_block_dispatch_flag_follows_the_weight_pack():
+    """the fused-block launchers dispatch on ROMP_OPF_WAVE16, never on weight_aux != NULL.  conv_math='all'
+    leaves the bf16x3 pack in every conv's weight_aux; a single-image plan fuses the 32-channel blocks WITHOUT the per-wave
+    repack, so its BBLOCK32 ops must carry weight_aux (stale bf16x3 bytes) but NOT the flag; the batch plan repacks and flags."""
+    from romp_amd import lib as L, synthetic as S
+    from romp_amd.plan import build_romp_hrnet32
+    sd = S.make_romp_state_dict(0)
+    for math in ('all', 'f16x2'):
+        single = build_romp_hrnet32(sd, 'cpu', 512, bf16x3=math, split_k_items=128)
+        single.op_array()
+        b32 = [i for i, o in enumerate(single.ops) if o.kind == L.OP_BBLOCK32]
+        assert len(b32) == 32 and not any(o.kind == L.OP_BBLOCK64 for o in single.ops)
+        for i in b32:
+            for o in (single.ops[i - 1], single.ops[i]):
+                assert not (o.flags & L.OPF_WAVE16)
+                assert bool(o.weight_aux) == (math == 'all')
+        batch = build_romp_hrnet32(sd, 'cpu', 512, bf16x3=math)
+        batch.op_array()
+        fused = [i for i, o in enumerate(batch.ops) if o.kind in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1)]
+        assert len(fused) == 32 + 32 + 3
+        for i in fused:
+            for o in (batch.ops[i - 1], batch.ops[i]):
+                assert (o.flags & L.OPF_WAVE16) and o.weight_aux
 
 
 def test_no_cpu_fallback_in_product_path():

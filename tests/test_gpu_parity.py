@@ -337,7 +337,9 @@ def test_net_range_calibration(dev):
 
 
 @pytest.mark.parametrize('B,H,Cc,impl', [(1, 32, 32, 'r'), (3, 64, 32, 'r'), (2, 48, 32, 'r'), (1, 32, 32, 'v1'), (3, 64, 32, 'v1'), (2, 48, 32, 'v1'),
-                                         (1, 16, 64, 'r'), (3, 64, 64, 'r'), (2, 48, 64, 'r')])
+                                         (1, 16, 64, 'r'), (3, 64, 64, 'r'), (2, 48, 64, 'r'),
+                                         # the production shapes (VERDICT r3 weak #1b): 128^2 x 32 (stage 2-4 branch 0) and 64^2 x 64 (branch 1)
+                                         (2, 128, 32, 'r'), (2, 128, 32, 'v1'), (2, 64, 64, 'r')])
 def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
     """csrc/conv_h2b.hip ('v1', 32 channels) / conv_h2c.hip ('r', 32 and 64 channels): a BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
     ordinary conv producing the H2 block input, then the block -- lowered by plan.py (which must fuse the pair), run through
@@ -368,9 +370,10 @@ def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
     assert P.fused_blocks == 1 and [o.kind for o in P.ops] == [L.OP_CONV, L.OP_NOP, fused_kind], [o.kind for o in P.ops]
     assert P.ops[2].out_fmt == L.FMT_H2
     if impl == 'v1':                                         # conv_h2b.hip's 16x16-tile kernel (single-image plans): no per-wave weight packs
-        ops[1].weight_aux = ops[2].weight_aux = None
+        ops[1].flags &= ~L.OPF_WAVE16
+        ops[2].flags &= ~L.OPF_WAVE16
     else:                                                    # conv_h2c.hip's row-pipelined kernels
-        assert ops[1].weight_aux and ops[2].weight_aux
+        assert ops[1].weight_aux and ops[2].weight_aux and (ops[1].flags & ops[2].flags & L.OPF_WAVE16)
     lib = L.load()
     h = C.c_void_p()
     sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
@@ -777,6 +780,127 @@ def test_net_benchmark_batch_vs_oracle(dev, B, conv_math):
     assert ev < 1e-4 and ee < 1e-3
 
 
+@pytest.mark.parametrize('kernel', ['mfma', 'valu'])
+@pytest.mark.parametrize('B,H,W', [(1, 64, 64), (3, 96, 64)])
+def test_stem_mfma_vs_torch(dev, kernel, B, H, W):
+    """The stem in isolation (model.py:384-387: x / 255 * 2 - 1, conv 3x3 s2 3 -> 64, BN, ReLU) against F.conv2d with the
+    normalisation: stem_mfma_kernel (K = 27 as one f16x2 MFMA step, H2 output -- the default path) and stem_conv_kernel (float32
+    VALU; ROMP_OPF_STEM_VALU), image borders included (every tile of these sizes touches one), B in {1, 3}, a non-square frame.
+    Also: a checkpoint whose stem weights do not fit the MFMA form's fp16 pieces is lowered onto the VALU kernel."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, assign_formats, set_conv_math, decode_h2, ACT_SHIFT
+    g = torch.Generator().manual_seed(11 * B + H)
+    img = torch.rand(B, H, W, 3, generator=g) * 255.0
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    ref = F.conv2d((img / 255.0 * 2.0 - 1.0).permute(0, 3, 1, 2), w, None, stride=2, padding=1)
+    ref = torch.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    P.stem('stem', w, scale, shift, H, W)
+    op = P.ops[0]
+    assert not (op.flags & L.OPF_STEM_VALU), 'ordinary weights take the MFMA stem'
+    op.out_fmt, op.act_shift = L.FMT_H2, ACT_SHIFT
+    if kernel == 'valu':
+        op.flags |= L.OPF_STEM_VALU
+    lib = L.load()
+    out = torch.full((B, H // 2, W // 2, 64), float('nan'), device=dev)
+    L.check(lib.romp_conv_forward(C.byref(op), L.ptr(img.to(dev).contiguous()), None, L.ptr(out), B, 0, -1, L.stream_ptr(dev)))
+    torch.cuda.synchronize()
+    err = (decode_h2(out.cpu()) - ref).abs().max().item()
+    print(f'stem {kernel} B={B} {H}x{W}: max-abs err {err:.3e} (ref absmax {ref.abs().max():.2f})')
+    assert err < 3e-5, err
+    big = Program(dev)
+    set_conv_math(big, 'f16x2')
+    big.stem('stem', w * 2000.0, scale, shift, H, W)
+    assert big.ops[0].flags & L.OPF_STEM_VALU, '256 |w| beyond fp16: the plan must pick the float32 stem'
+
+
+@pytest.mark.parametrize('max_batch', [1, 2])
+def test_net_conv_math_all_single_image(dev, max_batch):
+    """conv_math='all' in a single-image plan: every conv carries the bf16x3 pack in weight_aux, the
+    32-channel blocks are fused WITHOUT the per-wave repack -- the fused launcher must dispatch on ROMP_OPF_WAVE16, not on
+    weight_aux != NULL (it used to run the row-pipelined kernel on bf16x3 bytes: silently wrong maps)."""
+    from romp_amd import lib as L
+    from romp_amd.net import RompNet
+    sd = O.make_romp_state_dict(0)
+    net = RompNet(sd, dev, max_batch=max_batch, bf16x3='all')
+    blocks = [o for o in net.program.ops if o.kind == L.OP_BBLOCK32]
+    assert len(blocks) == 32 and all(o.weight_aux and not (o.flags & L.OPF_WAVE16) for o in blocks), 'single-image plan: conv_h2b.hip kernel, stale bf16x3 pack in weight_aux'
+    img = O.make_images(max_batch, seed=5)
+    cm_o, pm_o = O.romp_net_forward(sd, img)
+    cm, pm = net(img.to(dev))
+    ec, ep = (cm.cpu() - cm_o).abs().max().item(), (pm.cpu() - pm_o).abs().max().item()
+    print(f"conv_math='all' max_batch={max_batch}: center {ec:.3e} params {ep:.3e}")
+    assert ec < 1e-4 and ep < 1e-4
+
+
+def test_net_saturation_is_observable(dev):
+    """out-of-calibration values saturate at 65504 / 2^act_shift -- finite but wrong -- and that must not be silent.
+    The blown-up-BN net WITHOUT calibration reports saturation events (net.saturated > 0, range_scan names ops), in the default
+    build and in the checked build of the fused kernels; the ordinary net, and the blown-up net WITH calibration, report 0."""
+    from romp_amd.net import RompNet
+    sd = O.make_romp_state_dict(0)
+    img = O.make_images(2, seed=3).to(dev)
+    ok = RompNet(sd, dev, max_batch=2, bf16x3='f16x2')
+    ok(img)
+    assert ok.saturated == 0
+    rows = ok.range_scan(img)
+    assert sum(r[3] for r in rows) == 0 and sum(r[2] for r in rows) == 0 and ok.saturated == 0
+    big = {k: v.clone() for k, v in sd.items()}
+    key_w = [k for k in big if k.endswith('bn2.weight') and k.count('.') <= 2][0]
+    big[key_w] *= 3e3
+    big[key_w.replace('weight', 'bias')] *= 3e3
+    raw = RompNet(big, dev, max_batch=2, bf16x3='f16x2', calibrate=False)
+    assert raw.saturated == 0
+    raw(img)
+    n_default = raw.saturated
+    assert n_default > 0, 'the generic kernels count clamps in every build'
+    assert raw.reset_saturated() == n_default and raw.saturated == 0
+    rows = raw.range_scan(img)                              # checked builds of the fused kernels
+    hot = [(n, m, s) for n, m, b, s in rows if s]
+    print('default build: %d events; scan: %d ops clamped, first %s' % (n_default, len(hot), hot[:3]))
+    assert len(hot) > 3 and raw.saturated >= n_default
+    raw.set_sat_check(True)
+    raw.reset_saturated()
+    raw(img)
+    assert raw.saturated >= n_default
+    cal = RompNet(big, dev, max_batch=2, bf16x3='f16x2')    # calibrated: the blown-up tensors stay float32 -> nothing clamps
+    cal(img)
+    assert cal.saturated == 0 and len(cal.range_fallback) > 10
+
+
+def test_net_committed_table_all_images_vs_oracle(dev):
+    """The EXACT kernels the driver's bench line times (VERDICT r3 weak #1a): romp_amd/tune/romp_hrnet32_f16x2_b32.json installed
+    (it must resolve op for op in this build -- regenerate it with scripts/gpu_retune.sh after changing the plan or the variant
+    list), then ALL 32 images' maps against the oracle (1e-4) and every image's detections against the oracle's parse."""
+    import romp_amd
+    from romp_amd import tuning
+    B = 32
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh, settings.max_batch, settings.conv_math = 0, 1.3, B, 'f16x2'
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=O.make_synthetic_smpl(0))
+    ok, why = tuning.install_table(model.model, B, tuning.default_table_path('hrnet32', 'f16x2', B))
+    assert ok, 'the committed variant table does not fit this build: %s' % why
+    names = model.model.variant_names(B)
+    img = O.make_images(B, seed=1)
+    x = img.to(dev)
+    cm, pm = model.model(x)
+    cm_o, pm_o = O.romp_net_forward(sd, img)
+    ec = (cm.cpu() - cm_o).abs().amax(dim=(1, 2, 3))
+    ep = (pm.cpu() - pm_o).abs().amax(dim=(1, 2, 3))
+    print(f'committed table, {len(set(n for n in names if n.startswith("conv_")))} conv variants: worst image center {ec.max():.3e} params {ep.max():.3e}')
+    assert ec.max().item() < 1e-4 and ep.max().item() < 1e-4
+    out, bids = model.forward_batch(x)
+    ref = O.parsing_outputs(cm_o.numpy(), pm_o.numpy(), settings.center_thresh)
+    assert out is not None and ref is not None
+    assert np.array_equal(bids.cpu().numpy(), ref['batch_ids']), 'per-image detection counts differ'
+    assert np.array_equal(out['center_preds'].cpu().numpy(), ref['center_preds'])
+    assert model.model.saturated == 0
+
+
 # ------------------------------------------------------------------------------ end to end
 def test_romp_api_end_to_end(dev):
     """romp.ROMP(settings)(image) dict contract + parity of every gated output
@@ -889,7 +1013,7 @@ def test_graph_cache_is_bounded(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,H', [(1, 16), (3, 32)])
+@pytest.mark.parametrize('B,H', [(1, 16), (3, 32), (2, 128)])            # (2, 128): layer1's production shape
 def test_seam1x1(dev, B, H, monkeypatch):
     """csrc/conv_h2x.hip: the 1x1 64 -> 256 (+ residual + ReLU) / 1x1 256 -> 64 (+ ReLU) pair across
     a Bottleneck seam as one launch: both output tensors against torch on the CPU."""
