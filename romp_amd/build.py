@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libromp_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_f32.hip', 'conv_bx3.hip', 'conv_h2.hip', 'conv_h2d.hip', 'conv_h2r.hip', 'conv_h2b.hip', 'conv_h2c.hip', 'conv_h2x.hip', 'stem_fuse.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip', 'post.hip', 'render.hip', 'temporal.hip']
+SOURCES = ['conv_mfma.hip', 'conv_f32.hip', 'conv_bx3.hip', 'conv_h2.hip', 'conv_h2d.hip', 'conv_h2r.hip', 'conv_h2s.hip', 'conv_h2b.hip', 'conv_h2c.hip', 'conv_h2x.hip', 'stem_fuse.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip', 'post.hip', 'render.hip', 'temporal.hip']
 # conv_h2b's tile loop is ONE fully unrolled body (270 MFMAs with a step of side work after each): beyond the default budget of `#pragma unroll`
 EXTRA_FLAGS = {'conv_h2b.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'], 'conv_h2c.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
@@ -27,11 +27,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), lib=None, objdir=None):
+    """`extra_flags` / `lib` / `objdir`: a second, differently compiled library next to the product one (debug A/B builds,
+    loaded through env ROMP_HIP_LIB)."""
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
               [os.path.join(HERE, '..', 'include', 'romp_hip.h')]
-    objdir = os.path.join(HERE, 'build')
+    objdir = objdir or os.path.join(HERE, 'build')
+    lib = lib or LIB
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in SOURCES:
@@ -42,7 +45,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
@@ -53,12 +56,12 @@ def build(force=False, verbose=False):
     with cf.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr[-4000:])
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':

@@ -73,19 +73,41 @@ __device__ __forceinline__ void sat_report(int* counter, float mx) {
     if (counter && __builtin_amdgcn_ballot_w64(mx >= H2_MAX) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1);
 }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// fp16x2 of (a - hi.x, b - hi.y): the low pieces of two values whose packed high pieces are `hi`.  ONE asm block (v_fma_mix_f32 takes an
+// fp16 operand as it is; hipcc turns `x - (float)h` into a convert and a subtract, and follows every single-instruction asm whose result
+// is used at once with an s_nop): 3 instructions per value pair instead of 6.  The difference is exact in float32, so the result
+// is the one the plain C form gives.
+__device__ __forceinline__ unsigned h2_low_pair(unsigned hi, float a, float b) {
+    unsigned lo;
+    float ta, tb;
+    asm("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %0, %1, %2"
+        : "=v"(lo), "=&v"(ta), "=&v"(tb) : "v"(hi), "v"(a), "v"(b));
+    return lo;
+}
+__device__ __forceinline__ unsigned h2_high_pair(float a, float b) {      // v_cvt_pk_f16_f32: round to nearest even
+    typedef float f32x2_p __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_p __attribute__((ext_vector_type(2)));
+    const f32x2_p v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_p));
+}
 __device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo, float& mx) {
     const float s[4] = {v.x * act_scale, v.y * act_scale, v.z * act_scale, v.w * act_scale};
     sat_track(mx, s[0], s[1]);
     sat_track(mx, s[2], s[3]);
     const float x[4] = {h2_sat(s[0]), h2_sat(s[1]), h2_sat(s[2]), h2_sat(s[3])};
-    f16x4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = (_Float16)x[e];                       // round to nearest even
-        l[e] = (_Float16)(x[e] - (float)h[e]);       // the subtraction is exact
-    }
-    hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
+    // Packed conversions (v_cvt_pk_f16_f32), plain C for the low pieces.  NOT h2_low_pair's asm block here: round 4 measured it in
+    // this shared epilogue and the heavily spilling conv_h2_kernel<1,1,4,2,32,32> (784 bytes of scratch per lane) then faulted on
+    // the head's 64 -> 142 conv -- in the scalar-store path that never executes the block; the plain form of the same arithmetic
+    // does not (scripts/gpu_r4g.sh isolates it).  The fused kernels keep the asm: they do not spill.
+    typedef float f32x2_p __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_p __attribute__((ext_vector_type(2)));
+    const f16x2_p h0 = __builtin_convertvector((f32x2_p){x[0], x[1]}, f16x2_p), h1 = __builtin_convertvector((f32x2_p){x[2], x[3]}, f16x2_p);
+    const f16x2_p l0 = __builtin_convertvector((f32x2_p){x[0] - (float)h0[0], x[1] - (float)h0[1]}, f16x2_p);      // the subtractions are exact
+    const f16x2_p l1 = __builtin_convertvector((f32x2_p){x[2] - (float)h1[0], x[3] - (float)h1[1]}, f16x2_p);
+    hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 __device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, uint2& lo) {
     float mx = 0.f;
@@ -344,7 +366,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
 
 typedef void (*conv_fn)(ConvParams);
 // math: 0 f32 MFMA, 1 bf16x3 (register-staged weights), 2 bf16x3 (LDS-DMA weight rows), 3 / 4 the same two for f16x2,
-// 8 f16x2 with register-resident weights (conv_h2r.hip).  (5 / 6 / 7 were round 2's LDS-DMA pipeline kernels, now
+// 8 f16x2 with register-resident weights (conv_h2r.hip), 9 its stride-2 form on parity planes (conv_h2s.hip).  (5 / 6 / 7 were round 2's LDS-DMA pipeline kernels, now
 // scripts/attic/conv_h2p.hip: never faster than 3 / 4 / 8 inside the network.)  threads: workgroup size (0 = 256, or 512 for the ping-pong kernels).
 // o4: the same kernel compiled for four workgroups per CU (128 VGPRs; named conv_h2o).
 struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; int threads; int o4; };
@@ -355,5 +377,6 @@ ConvVariant* conv_variants_bx3(int* n);
 ConvVariant* conv_variants_h2(int* n);
 ConvVariant* conv_variants_h2d(int* n);
 ConvVariant* conv_variants_h2r(int* n);
+ConvVariant* conv_variants_h2s(int* n);
 
 }  // namespace romp

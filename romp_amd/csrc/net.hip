@@ -508,9 +508,18 @@ int romp_net_autotune(romp_net* n, int B, int iters, void* stream) {
     for (size_t i = 0; i < n->ops.size() && rc == ROMP_OK; ++i) {
         const romp_op& op = n->ops[i];
         if (op.kind != ROMP_OP_CONV) continue;
+        { static const char* only = getenv("ROMP_AUTOTUNE_ONLY_OP");                 // debugging aid: measure one op only
+          if (only && atoi(only) != (int)i) continue; }
         float best_ms = 1e30f;
+        static const bool verbose = getenv("ROMP_AUTOTUNE_VERBOSE") != nullptr;      // debugging aid: names the launch a GPU fault belongs to
         for (int v = 0; v < conv_num_variants(); ++v) {
             if (!conv_variant_tunable(op, v)) continue;
+            if (verbose) {
+                char name[128] = "?";
+                describe_conv(op, B, v, name, sizeof(name));
+                fprintf(stderr, "autotune: op %zu (H %d Cin %d Cout %d k%d s%d g%d) variant %d %s\n", i, op.H, op.Cin, op.Cout, op.ksize, op.stride, op.groups, v, name);
+                fflush(stderr);
+            }
             float ms_min = 1e30f;
             for (int it = 0; it < iters + 1 && rc == ROMP_OK; ++it) {
                 rc = reset_queues(n, st);

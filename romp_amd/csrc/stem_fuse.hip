@@ -482,7 +482,7 @@ int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H,
 // 1/G of the loop) into G float32 partial tensors; this kernel adds them in slice order and applies the layer's epilogue.
 struct KsumParams {
     const float* part; const float* res; const float* scale; const float* shift; float* out;
-    int G, C, C8, part_cs, res_cs, res_co, out_cs, out_co, relu, res_h2, out_h2;
+    int G, C, C8, part_cs, res_cs, res_co, out_cs, out_co, relu, relu_from, res_h2, out_h2;
     float act_scale, inv_act_scale; size_t total;
     int* sat;
 };
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void ksum_kernel(KsumParams p) {
             va.x += ra.x; va.y += ra.y; va.z += ra.z; va.w += ra.w;
             vb.x += rb.x; vb.y += rb.y; vb.z += rb.z; vb.w += rb.w;
         }
-        if (p.relu) {
+        if (p.relu && c >= p.relu_from) {
             va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
             vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
         }
@@ -557,6 +557,7 @@ int launch_ksum(const romp_op& op, const float* partial, const float* res, float
     p.part = partial; p.res = res; p.scale = (const float*)op.scale; p.shift = (const float*)op.shift; p.out = out;
     p.G = op.groups; p.C = op.Cout; p.C8 = op.Cout / 8; p.part_cs = op.in_cstride;
     p.res_cs = op.res_cstride; p.res_co = op.res_coff; p.out_cs = op.out_cstride; p.out_co = op.out_coff; p.relu = op.relu;
+    p.relu_from = op.relu ? op.relu_from : 0;
     p.res_h2 = op.res_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2;
     p.act_scale = ldexpf(1.f, op.act_shift); p.inv_act_scale = ldexpf(1.f, -op.act_shift);
     p.sat = conv_sat_counter();

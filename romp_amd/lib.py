@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libromp_hip.so')
+LIB_PATH = os.environ.get('ROMP_HIP_LIB') or os.path.join(_HERE, 'libromp_hip.so')     # (ROMP_HIP_LIB: a debug build of the same ABI)
 
 ABI_VERSION = 5          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4

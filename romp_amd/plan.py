@@ -64,7 +64,9 @@ def conv_pads(cin, cout, ksize):
         ck = 32 if cin % 32 == 0 else 16
     else:                                   # 3 (3x3), 2 (2x2) and 13 (1x3, Conv1d)
         ck = 16 if cin % 16 == 0 else 8
-    return _round_up(cin, ck), _round_up(cout, 64 if cout >= 64 else 32)
+    # (a merged sibling conv may have 96 output channels: three whole 32-wide blocks, no padding -- padded channels would cost the
+    # vector epilogue and with it the H2 output)
+    return _round_up(cin, ck), _round_up(cout, 64 if (cout >= 64 and cout % 32) or cout % 64 == 0 else 32)
 
 
 def pack_conv_weight(w, cin_pad, cout_pad):
@@ -215,7 +217,7 @@ def assign_formats(P):
             for k in range(op.n_terms):
                 g = gen_for_read(op.term_buf[k])
                 g['uses'].append((i, ('term', k)))
-                g['ok'] &= oct_ok(op.term_cstride[k])
+                g['ok'] &= oct_ok(op.term_cstride[k], op.term_coff[k])
             g = gen_for_write(op.out_buf)
             g['uses'].append((i, 'out'))
             g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
@@ -481,9 +483,11 @@ class Program:
 
     def conv(self, name, x: Act, w, scale, shift, ksize, stride, relu, res: Optional[Act] = None,
              out: Optional[Act] = None, groups=1, out_buf_special=None, out_cstride=None, out_coff=0,
-             pad=(-1, -1), out_rstride=0, out_bstride=0):
+             pad=(-1, -1), out_rstride=0, out_bstride=0, relu_from=0):
         """One conv layer; in a single-image plan (split_k_items) a layer with few pixels and many input channels becomes a
-        grouped conv over input-channel slices writing float32 partial sums + a ksum op with the layer's epilogue."""
+        grouped conv over input-channel slices writing float32 partial sums + a ksum op with the layer's epilogue.
+        `relu_from` (with relu): ReLU on output channels >= relu_from only (merged sibling convs, a multiple of 32)."""
+        assert relu_from == 0 or (relu and relu_from % 32 == 0 and groups == 1), relu_from
         G = 1
         if groups == 1 and out_buf_special is None and not out_rstride and not out_bstride and tuple(pad) == (-1, -1) and x.coff % 8 == 0:
             cout, cin = w[0].shape[0], w[0].shape[1]
@@ -491,8 +495,10 @@ class Program:
                 Ho = (x.H + 2 * (ksize // 2) - ksize) // stride + 1
                 G = self.split_k_groups(cin, cout, ksize, stride, Ho, (x.W + 2 * (ksize // 2) - ksize) // stride + 1)
         if G == 1:
-            return self._conv_op(name, x, w, scale, shift, ksize, stride, relu, res, out, groups, out_buf_special, out_cstride,
-                                 out_coff, pad, out_rstride, out_bstride)
+            o = self._conv_op(name, x, w, scale, shift, ksize, stride, relu, res, out, groups, out_buf_special, out_cstride,
+                              out_coff, pad, out_rstride, out_bstride)
+            self.ops[-1].relu_from = relu_from
+            return o
         cg = cin // G
         part = self._conv_op(name + '.splitk', x, [w[0][:, g * cg:(g + 1) * cg].contiguous() for g in range(G)],
                              [torch.ones(cout)] * G, [torch.zeros(cout)] * G, ksize, stride, False, groups=G)
@@ -506,6 +512,7 @@ class Program:
             op.res_cstride, op.res_coff = res.cstride, res.coff
         ps, pb = self._dev(scale[0].float()), self._dev(shift[0].float())
         op.scale, op.shift = ps.data_ptr(), pb.data_ptr()
+        op.relu_from = relu_from
         op.stream = self.cur_stream
         self.ops.append(op)
         self.names.append(name + '.ksum')
@@ -607,8 +614,8 @@ class Program:
         op.n_terms = len(terms)
         nbytes = 4.0 * H * W * t0.C
         for k, (t, s) in enumerate(zip(terms, shifts)):
-            assert t.C == t0.C and t.coff == 0 and (t.H << s) == H
-            op.term_buf[k], op.term_shift[k], op.term_cstride[k] = t.buf, s, t.cstride
+            assert t.C == t0.C and t.coff % 8 == 0 and (t.H << s) == H
+            op.term_buf[k], op.term_shift[k], op.term_cstride[k], op.term_coff[k] = t.buf, s, t.cstride, t.coff
             nbytes += 4.0 * t.H * t.W * t.C
         op.stream = self.cur_stream
         self.ops.append(op)
@@ -672,55 +679,84 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
           cbr('transition1.1', x, bb + 'transition1.1.0.0', bb + 'transition1.1.0.1', 3, 2, True)]
     P.free(x)
 
+    import os
+    merge_s2 = os.environ.get('ROMP_MERGE_S2', '1') != '0'       # A/B switch: 0 = one launch per stride-2 conv as in rounds 1-3
+
     def hr_module(prefix, xs, n_out, final_out: Optional[Act] = None):
         """HighResolutionModule.forward (model.py:226-244).  The branches are independent until the
         fuse (model.py:230-231) and so are the fuse outputs: each runs on its own HIP stream, so the
         persistent conv kernels of different branches share the CUs and fill each other's barrier /
-        load gaps and launch tails."""
+        load gaps and launch tails.
+
+        Region 1 (one stream per branch j): the 4 BasicBlocks, then everything of the fuse layers that reads ONLY xs[j]: the
+        FIRST stride-2 conv of every chain that starts at branch j (model.py:198-221) -- as ONE conv with concatenated output
+        channels when there are several (round 4: towards outputs j+1, j+2, j+3 they all read the same tensor; it is now read
+        once: [no-ReLU channels of the chain that ends here | ReLU channels of the longer chains], romp_op.relu_from) -- and the
+        1x1 up-convs towards the outputs above (model.py:186-196).  Region 2 (one stream per output i): the rest of the chains
+        and the sum."""
         nb = len(xs)
         xs = list(xs)
+        ch = [x.C for x in xs]
+        first, ups, temps = {}, {}, []                            # (i, j) -> Act
         P.fork(nb - 1)
-        for br in range(nb):                                     # branches: 4 BasicBlocks each
+        for br in range(nb):
             P.on(br)
-            for k in range(4):
+            for k in range(4):                                   # branch: 4 BasicBlocks
                 q = f'{prefix}branches.{br}.{k}.'
                 t = cbr(q + 'conv1', xs[br], q + 'conv1', q + 'bn1', 3, 1, True)
                 y = cbr(q + 'conv2', t, q + 'conv2', q + 'bn2', 3, 1, True, res=xs[br])
                 P.free(t)
                 P.free(xs[br])
                 xs[br] = y
+            targets = list(range(br + 1, n_out))                 # chains br -> i start with a conv on xs[br]
+            if len(targets) > 1 and merge_s2:
+                ws, ss, bs = [], [], []
+                for i in targets:                                # i = br + 1 first: its single conv is the chain's LAST (no ReLU)
+                    q = f'{prefix}fuse_layers.{i}.{br}.0.'
+                    w = sd[q + '0.weight']
+                    sc, sh = fold_bn(sd, q + '1', w.shape[0], sd.get(q + '0.bias'))
+                    ws.append(w); ss.append(sc); bs.append(sh)
+                name = f'{prefix}fuse_layers.{targets[0]}-{targets[-1]}.{br}.0'
+                m = P.conv(name, xs[br], [torch.cat(ws, 0)], [torch.cat(ss)], [torch.cat(bs)], 3, 2, True, relu_from=ws[0].shape[0])
+                temps.append(m)
+                off = 0
+                for i, w in zip(targets, ws):
+                    first[(i, br)] = Act(m.buf, w.shape[0], m.H, m.W, m.cstride, m.coff + off)
+                    off += w.shape[0]
+            else:
+                for i in targets:
+                    q = f'{prefix}fuse_layers.{i}.{br}.'
+                    first[(i, br)] = cbr(f'{q}0', xs[br], f'{q}0.0', f'{q}0.1', 3, 2, i - br != 1)
+                    temps.append(first[(i, br)])
+            for i in range(min(br, n_out)):                      # 1x1 conv + BN towards output i < br; the upsample is folded into fusesum
+                q = f'{prefix}fuse_layers.{i}.{br}.'
+                ups[(i, br)] = cbr(q + 'up', xs[br], q + '0', q + '1', 1, 1, False)
+                temps.append(ups[(i, br)])
         P.join()
-        outs, all_temps = [], []
-        by_output = n_out > 1
-        P.fork((n_out if by_output else nb) - 1)
-        pending = []
+        outs = []
+        P.fork(n_out - 1)
         for i in range(n_out):
+            P.on(i)
             terms, shifts = [], []
             for j in range(nb):
-                P.on(i if by_output else j)
                 q = f'{prefix}fuse_layers.{i}.{j}.'
                 if j == i:
                     terms.append(xs[j]); shifts.append(0)
-                elif j > i:                                      # 1x1 conv + BN, upsample folded into fusesum
-                    t = cbr(q + 'up', xs[j], q + '0', q + '1', 1, 1, False)
-                    terms.append(t); shifts.append(j - i); all_temps.append(t)
-                else:                                            # chain of stride-2 3x3 convs
-                    t = xs[j]
-                    for k in range(i - j):
+                elif j > i:
+                    terms.append(ups[(i, j)]); shifts.append(j - i)
+                else:                                            # the rest of the chain of stride-2 3x3 convs
+                    t = first[(i, j)]
+                    for k in range(1, i - j):
                         t2 = cbr(f'{q}{k}', t, f'{q}{k}.0', f'{q}{k}.1', 3, 2, k != i - j - 1)
-                        if t is not xs[j]:
+                        if k > 1:
                             P.free(t)
                         t = t2
-                    terms.append(t); shifts.append(0); all_temps.append(t)
-            if by_output:                                        # the sum follows its terms on the same stream
-                P.on(i)
-                outs.append(P.fusesum(f'{prefix}fuse.{i}', terms, shifts, True))
-            else:
-                pending.append((terms, shifts))
+                    if i - j > 1:
+                        temps.append(t)
+                    terms.append(t); shifts.append(0)
+            outs.append(P.fusesum(f'{prefix}fuse.{i}', terms, shifts, True, out=final_out if n_out == 1 else None))
         P.join()
-        for terms, shifts in pending:                            # single output: terms ran in parallel, sum after the join
-            outs.append(P.fusesum(f'{prefix}fuse.0', terms, shifts, True, out=final_out))
-        for t in all_temps:
+        for t in temps:
             P.free(t)
         for xj in xs:
             P.free(xj)

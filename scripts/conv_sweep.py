@@ -9,7 +9,8 @@ import torch
 
 CASES = {
     's1': [(32, 32, 3, 1, 128, True), (64, 64, 3, 1, 64, True), (128, 128, 3, 1, 32, True), (256, 256, 3, 1, 16, True)],
-    's2': [(32, 64, 3, 2, 128, False), (64, 128, 3, 2, 64, False), (128, 256, 3, 2, 32, False), (64, 64, 3, 2, 256, False)],
+    's2': [(32, 64, 3, 2, 128, False), (64, 128, 3, 2, 64, False), (128, 256, 3, 2, 32, False), (64, 64, 3, 2, 256, False),
+           (32, 128, 3, 2, 128, False), (32, 96, 3, 2, 128, False), (64, 192, 3, 2, 64, False), (256, 64, 3, 2, 128, False), (48, 192, 3, 2, 128, False)],
     'k1': [(64, 256, 1, 1, 128, False), (256, 64, 1, 1, 128, True), (64, 64, 1, 1, 128, False)],
 }
 

@@ -95,6 +95,11 @@ def run(case, B, tags):
 if __name__ == '__main__':
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     tags = sys.argv[2:]
+    if os.environ.get('TRACE_CASES'):            # "cin,cout,k,s,H,res;..." e.g. TRACE_CASES="32,128,3,2,128,0;64,64,3,2,256,0"
+        for c in os.environ['TRACE_CASES'].split(';'):
+            v = [int(t) for t in c.split(',')]
+            run((v[0], v[1], v[2], v[3], v[4], bool(v[5])), B, tags or ['h2s'])
+        sys.exit(0)
     cases = [((32, 32, 3, 1, 128, True), tags or ['h2_k3s1_mt1_nt1_tw16', 'h2d_k3s1_mt2_nt1_tw32']),
              ((64, 64, 3, 1, 64, True), tags or ['h2_k3s1_mt1_nt2_tw16', 'h2d_k3s1_mt2_nt2_tw16_ck16']),
              ((128, 128, 3, 1, 32, True), tags or ['h2_k3s1_mt1_nt2_tw16']),

@@ -160,7 +160,9 @@ CONV_CASES = [
     (256, 256, 3, 1, 16, True, True), (256, 32, 3, 1, 128, True, False), (64, 64, 3, 2, 256, True, False),
     (256, 64, 3, 2, 128, True, False), (32, 64, 3, 2, 128, False, False), (32, 32, 3, 2, 128, True, False),
     (64, 128, 3, 2, 64, False, False), (128, 256, 3, 2, 32, False, False), (32, 256, 3, 2, 32, False, False),
-    (40, 192, 3, 2, 128, True, False),
+    (40, 192, 3, 2, 128, True, False), (48, 192, 3, 2, 128, True, False),
+    # merged sibling convs of the fuse layers (plan.hr_module, romp_op.relu_from): [no-ReLU channels | ReLU channels]
+    (32, 96, 3, 2, 128, True, False, 64), (32, 128, 3, 2, 128, True, False, 64), (64, 192, 3, 2, 64, True, False, 128),
     (64, 64, 1, 1, 128, True, False), (64, 256, 1, 1, 128, False, False), (256, 64, 1, 1, 128, True, True),
     (64, 32, 1, 1, 64, False, False), (128, 32, 1, 1, 32, False, False), (256, 128, 1, 1, 16, False, False),
     (64, 142, 1, 1, 64, False, False), (64, 1, 1, 1, 64, False, False), (64, 3, 1, 1, 64, False, False),
@@ -177,7 +179,8 @@ def test_conv_layer(dev, case, B, fmt):
     import ctypes as C
     from romp_amd import lib as L
     from romp_amd.plan import Program, Act, set_conv_math, encode_h2, decode_h2, ACT_SHIFT
-    cin, cout, k, s, H, relu, use_res = case
+    cin, cout, k, s, H, relu, use_res = case[:7]
+    relu_from = case[7] if len(case) > 7 else 0
     g = torch.Generator().manual_seed(cin * 1000 + cout + k + s + H)
     x = torch.randn(B, H, H, cin, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
@@ -190,7 +193,7 @@ def test_conv_layer(dev, case, B, fmt):
     if res is not None:
         ref = ref + res.permute(0, 3, 1, 2)
     if relu:
-        ref = torch.relu(ref)
+        ref = torch.cat([ref[:, :relu_from], torch.relu(ref[:, relu_from:])], 1)
     ref = ref.permute(0, 2, 3, 1)
     P = Program(dev)
     set_conv_math(P, 'all')              # pack the split weights too: bf16x3 and f16x2 variants join the sweep below
@@ -200,8 +203,9 @@ def test_conv_layer(dev, case, B, fmt):
     if res is not None:
         P.buf_floats.append(cout * Ho * Ho)
         ra = Act(1, cout, Ho, Ho, cout)
-    P.conv('t', xa, [w], [scale], [shift], k, s, relu, res=ra)
+    P.conv('t', xa, [w], [scale], [shift], k, s, relu, res=ra, relu_from=relu_from)
     op = P.ops[0]
+    assert op.relu_from == relu_from
     out_h2 = False
     if fmt == 'h2':
         if cin % 8 or not op.weight_h2:
@@ -850,8 +854,8 @@ def test_net_saturation_is_observable(dev):
     assert sum(r[3] for r in rows) == 0 and sum(r[2] for r in rows) == 0 and ok.saturated == 0
     big = {k: v.clone() for k, v in sd.items()}
     key_w = [k for k in big if k.endswith('bn2.weight') and k.count('.') <= 2][0]
-    big[key_w] *= 3e3
-    big[key_w.replace('weight', 'bias')] *= 3e3
+    big[key_w] *= 3e4                                       # stem conv2's BN: everything downstream ~3e4 x larger (fp16 pieces of 16 x end at 4094)
+    big[key_w.replace('weight', 'bias')] *= 3e4
     raw = RompNet(big, dev, max_batch=2, bf16x3='f16x2', calibrate=False)
     assert raw.saturated == 0
     raw(img)
