@@ -46,6 +46,7 @@ struct ConvParams {
                               // clamped a value at +-65504 while splitting it into fp16 pieces (h2_sat): out-of-calibration activations
     int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
+                              // 512 (h2r / h2s, correct outputs) the LDS-transposed epilogue instead of the direct one,
                               // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
                               // only the pixel loads / only the weight DMA.  scripts/conv_ablate.py and DESIGN.md §4 use them.
 };
@@ -362,6 +363,90 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const Item& c
                                               const float* sSc, char* sE, int wave, int li, int lh) {
     EpiRes<MT, NT> none;
     conv_epilogue<KS, S, MT, NT, TW, CK, NWV>(p, cur, acc, sSc, sE, wave, li, lh, none, false);
+}
+
+// ---- the direct H2 epilogue (round 4; conv_h2r.hip / conv_h2s.hip) ----------------------------------------------------------
+// The phase traces of the register-weight kernels put 25-30 % of a work item into conv_epilogue above: four 16-byte LDS stores, a
+// wave barrier and four loads per 32 x 32 block just to re-own the accumulators, the split as ~7 VALU per value, a uniform branch per
+// option.  For the one case those kernels almost always run -- H2 output, no residual or an H2 residual -- nothing needs to move
+// through LDS: the MFMA leaves lane (li, lh) with channels 8 g4 + 4 lh .. + 3 of pixel li, i.e. HALF of octet g4; the lane splits
+// its four values (packed conversions: 2 instructions per value), and one v_permlane32_swap pair trades halves with lane li of the
+// other half-wave so that each lane holds one whole 16-byte unit (lower half-wave: the octet's eight high pieces, upper: the low
+// pieces) and stores it: 32 contiguous bytes per lane pair, the four g4 steps of a block fill each pixel's 128-byte line.  The
+// residual comes in the same way in reverse (one 16-byte unit per lane, two swaps).  Values are formed in the scaled domain
+// (scale and shift pre-multiplied by 2^act_shift, as in the fused-block kernels).
+__device__ __forceinline__ float h2_add_pieces_clamp(float x, unsigned rh, unsigned rl, int half, float lo_b, float top) {
+    float d;                      // min(max(x + piece `half` of rh + piece `half` of rl, lo_b), top)
+    if (half == 0)
+        asm("v_fma_mix_f32 %0, %1, 1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_med3_f32 %0, %0, %4, %5" : "=&v"(d) : "v"(rh), "v"(rl), "v"(x), "v"(lo_b), "v"(top));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_med3_f32 %0, %0, %4, %5" : "=&v"(d) : "v"(rh), "v"(rl), "v"(x), "v"(lo_b), "v"(top));
+    return d;
+}
+
+template <int KS, int S, int MT, int TW, int NWV>
+__device__ __forceinline__ void conv_epilogue_h2direct(const ConvParams& p, const Item& cur, f32x16 (&acc)[MT][1], const float* sSc,
+                                                       int wave, int li, int lh) {
+    using C = ConvCfg<KS, S, MT, 1, TW, 16, NWV>;
+    typedef unsigned u32x2_e __attribute__((ext_vector_type(2)));
+    float* out = p.out + (size_t)cur.b * p.out_bs + p.out_co + cur.g * p.out_gs + cur.n0 + lh * 4;
+    const float* res = p.res ? p.res + (size_t)cur.b * p.Ho * p.Wo * p.res_cs + p.res_co + cur.g * p.res_gs + cur.n0 + lh * 4 : nullptr;
+    const float lo_b = (p.relu && cur.n0 >= p.relu_from) ? 0.f : -H2_MAX;
+    unsigned pixo[MT], outo[MT];
+    bool rowok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mb = wave * MT + m;
+        const int oy = cur.ty * C::TH + mb * C::RPB + li / TW, ox = cur.tx * TW + li % TW;
+        rowok[m] = oy < p.Ho;
+        pixo[m] = rowok[m] ? (unsigned)(oy * p.Wo + ox) : 0u;
+        outo[m] = rowok[m] ? (unsigned)(oy * p.out_rs + ox * p.out_cs) : 0u;
+    }
+    uint4 ru[MT][4];                                 // residual: this lane's unit (lower half-wave: high pieces, upper: low pieces) of octet g4
+    if (res) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) ru[m][g4] = *reinterpret_cast<const uint4*>(res + (pixo[m] * (unsigned)p.res_cs + (unsigned)(g4 * 8)));
+    }
+    float sat_mx = 0.f;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = g4 * 8 + lh * 4;
+        float4 sc = *reinterpret_cast<const float4*>(sSc + cl), sh = *reinterpret_cast<const float4*>(sSc + 32 + cl);
+        sc.x *= p.act_scale; sc.y *= p.act_scale; sc.z *= p.act_scale; sc.w *= p.act_scale;
+        sh.x *= p.act_scale; sh.y *= p.act_scale; sh.z *= p.act_scale; sh.w *= p.act_scale;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float v[4] = {fmaf(acc[m][0][g4 * 4 + 0], sc.x, sh.x), fmaf(acc[m][0][g4 * 4 + 1], sc.y, sh.y),
+                          fmaf(acc[m][0][g4 * 4 + 2], sc.z, sh.z), fmaf(acc[m][0][g4 * 4 + 3], sc.w, sh.w)};
+            if (res) {
+                // unit dwords (x, y, z, w) = pieces of channels (0,1) (2,3) (4,5) (6,7); after the swaps: a = high pieces, b = low pieces of
+                // THIS lane's channels (4 lh .. 4 lh + 3): [0] the first pair, [1] the second
+                const u32x2_e s0 = __builtin_amdgcn_permlane32_swap(ru[m][g4].x, ru[m][g4].z, false, false);
+                const u32x2_e s1 = __builtin_amdgcn_permlane32_swap(ru[m][g4].y, ru[m][g4].w, false, false);
+                v[0] = h2_add_pieces_clamp(v[0], s0[0], s0[1], 0, lo_b, H2_MAX);
+                v[1] = h2_add_pieces_clamp(v[1], s0[0], s0[1], 1, lo_b, H2_MAX);
+                v[2] = h2_add_pieces_clamp(v[2], s1[0], s1[1], 0, lo_b, H2_MAX);
+                v[3] = h2_add_pieces_clamp(v[3], s1[0], s1[1], 1, lo_b, H2_MAX);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo_b, H2_MAX);
+            }
+            sat_track(sat_mx, v[0], v[1]);            // (after the clamp: |v| == H2_MAX iff it clamped, or hit the limit exactly)
+            sat_track(sat_mx, v[2], v[3]);
+            const unsigned h0 = h2_high_pair(v[0], v[1]), h1 = h2_high_pair(v[2], v[3]);
+            const unsigned l0 = h2_low_pair(h0, v[0], v[1]), l1 = h2_low_pair(h1, v[2], v[3]);
+            const u32x2_e a = __builtin_amdgcn_permlane32_swap(h0, l0, false, false);
+            const u32x2_e b = __builtin_amdgcn_permlane32_swap(h1, l1, false, false);
+            if (rowok[m]) *reinterpret_cast<uint4*>(out + (outo[m] + (unsigned)(g4 * 8))) = make_uint4(a[0], b[0], a[1], b[1]);
+        }
+    }
+    sat_report(p.sat, sat_mx);
 }
 
 typedef void (*conv_fn)(ConvParams);

@@ -244,8 +244,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2s_kernel(ConvParams p) {
                 ce.n0 += sl * 32;
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));               // (see conv_h2r.hip: keeps the epilogue's address parts out of the stage loop)
-                conv_epilogue<3, 2, P, 1, TW, 16, PG>(p, ce, acc, reinterpret_cast<const float*>(sSb + slot * X::SS_BYTES) + sl * 64,
-                                                      sE, pg, lane_e & 31, lane_e >> 5);
+                const float* sc_e = reinterpret_cast<const float*>(sSb + slot * X::SS_BYTES) + sl * 64;
+                if (p.out_h2 && p.vec_io && (!p.res || p.res_h2) && !(p.dbg & 512)) conv_epilogue_h2direct<3, 2, P, TW, PG>(p, ce, acc, sc_e, pg, lane_e & 31, lane_e >> 5);
+                else conv_epilogue<3, 2, P, 1, TW, 16, PG>(p, ce, acc, sc_e, sE, pg, lane_e & 31, lane_e >> 5);
             }
 #pragma unroll
             for (int j = 0; j < P; ++j)

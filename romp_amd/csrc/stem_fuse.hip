@@ -390,61 +390,74 @@ int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStr
 
 struct FuseParams {
     const float* t[4]; int shift[4]; int cs[4]; int h2[4];        // (a term's channel offset is folded into its pointer)
-    float* out; int n_terms, H, W, C8, out_cs, out_co, relu, out_h2; float act_scale, inv_act_scale; size_t total;
+    float* out; int n_terms, H, W, C8, out_cs, out_co, relu, out_h2; float act_scale, inv_act_scale;
+    int rows_total, c8_shift;                                     // B * H output rows; log2(C8) when C8 and W are powers of two
     int* sat;
 };
 
 // One thread per pixel and channel OCTET (32 bytes in either format).  H2 terms are summed in the scaled domain
 // (x * 2^act_shift: exact, a power of two commutes with every f32 rounding), float32 terms are scaled on the way in.
+// Work mapping (round 4): a workgroup owns whole output ROWS (blockIdx -> (image, row): one scalar division per row), a thread's
+// (column, octet) comes from shifts -- W and C / 8 are powers of two in every HRNet fuse layer (`pow2` = 0: the general form with
+// divisions).  Round 3 derived (octet, x, y, image) from a flat index with four runtime integer divisions per 32 output bytes:
+// ~150 VALU instructions of index arithmetic per element had this streaming kernel at 3.7-4.0 TB/s.
+template <int POW2>
 __global__ __launch_bounds__(256) void fusesum_kernel(FuseParams p) {
     float sat_mx = 0.f;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < p.total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t r = i;
-        const int c = (int)(r % p.C8) * 8; r /= p.C8;
-        const int x = (int)(r % p.W); r /= p.W;
-        const int y = (int)(r % p.H);
-        const int b = (int)(r / p.H);
-        float4 va, vb;                                 // channels c..c+3, c+4..c+7 (scaled by act_scale when any H2 is involved)
-        const bool scaled = p.out_h2 || p.h2[0] || p.h2[1] || p.h2[2] || p.h2[3];
-        const float in_scale = scaled ? p.act_scale : 1.f;
+    const int per_row = p.W * p.C8;
+    const bool scaled = p.out_h2 || p.h2[0] || p.h2[1] || p.h2[2] || p.h2[3];
+    const float in_scale = scaled ? p.act_scale : 1.f;
+    for (int row = blockIdx.x; row < p.rows_total; row += gridDim.x) {
+        const int b = row / p.H, y = row - b * p.H;
+        const float* tp[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < p.n_terms) {
-                const int s = p.shift[k];
-                const int h = p.H >> s, w = p.W >> s;
-                const float* tp = p.t[k] + (((size_t)b * h + (y >> s)) * w + (x >> s)) * p.cs[k] + c;
-                const float4 u0 = *reinterpret_cast<const float4*>(tp), u1 = *reinterpret_cast<const float4*>(tp + 4);
-                float4 ta, tb;
-                if (p.h2[k]) {                         // u0 = eight high pieces, u1 = eight low pieces
-                    const uint4 hi = __builtin_bit_cast(uint4, u0), lo = __builtin_bit_cast(uint4, u1);
-                    ta = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), 1.f);
-                    tb = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), 1.f);
-                } else {
-                    ta = make_float4(u0.x * in_scale, u0.y * in_scale, u0.z * in_scale, u0.w * in_scale);
-                    tb = make_float4(u1.x * in_scale, u1.y * in_scale, u1.z * in_scale, u1.w * in_scale);
-                }
-                if (k == 0) { va = ta; vb = tb; }
-                else {
-                    va.x += ta.x; va.y += ta.y; va.z += ta.z; va.w += ta.w;
-                    vb.x += tb.x; vb.y += tb.y; vb.z += tb.z; vb.w += tb.w;
+        for (int k = 0; k < 4; ++k) {                 // the row of term k this output row reads
+            const int s = p.shift[k];
+            tp[k] = p.t[k] + ((size_t)b * (p.H >> s) + (y >> s)) * (size_t)(p.W >> s) * p.cs[k];
+        }
+        float* orow = p.out + ((size_t)b * p.H + y) * (size_t)p.W * p.out_cs + p.out_co;
+#pragma unroll 2
+        for (int i = threadIdx.x; i < per_row; i += blockDim.x) {
+            const int x = POW2 ? i >> p.c8_shift : i / p.C8;
+            const int c = (POW2 ? i & (p.C8 - 1) : i - x * p.C8) * 8;
+            float4 va, vb;                             // channels c..c+3, c+4..c+7 (scaled by act_scale when any H2 is involved)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < p.n_terms) {
+                    const float* q = tp[k] + (size_t)(x >> p.shift[k]) * p.cs[k] + c;
+                    const float4 u0 = *reinterpret_cast<const float4*>(q), u1 = *reinterpret_cast<const float4*>(q + 4);
+                    float4 ta, tb;
+                    if (p.h2[k]) {                     // u0 = eight high pieces, u1 = eight low pieces
+                        const uint4 hi = __builtin_bit_cast(uint4, u0), lo = __builtin_bit_cast(uint4, u1);
+                        ta = h2_unpack(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y), 1.f);
+                        tb = h2_unpack(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w), 1.f);
+                    } else {
+                        ta = make_float4(u0.x * in_scale, u0.y * in_scale, u0.z * in_scale, u0.w * in_scale);
+                        tb = make_float4(u1.x * in_scale, u1.y * in_scale, u1.z * in_scale, u1.w * in_scale);
+                    }
+                    if (k == 0) { va = ta; vb = tb; }
+                    else {
+                        va.x += ta.x; va.y += ta.y; va.z += ta.z; va.w += ta.w;
+                        vb.x += tb.x; vb.y += tb.y; vb.z += tb.z; vb.w += tb.w;
+                    }
                 }
             }
-        }
-        if (p.relu) {
-            va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
-            vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
-        }
-        float* op_ = p.out + (((size_t)b * p.H + y) * p.W + x) * p.out_cs + p.out_co + c;
-        if (p.out_h2) {
-            uint2 ha, la, hb, lb;
-            h2_pack(va, 1.f, ha, la, sat_mx);
-            h2_pack(vb, 1.f, hb, lb, sat_mx);
-            *reinterpret_cast<uint4*>(op_) = make_uint4(ha.x, ha.y, hb.x, hb.y);
-            *reinterpret_cast<uint4*>(op_ + 4) = make_uint4(la.x, la.y, lb.x, lb.y);
-        } else {
-            const float os = scaled ? p.inv_act_scale : 1.f;
-            *reinterpret_cast<float4*>(op_) = make_float4(va.x * os, va.y * os, va.z * os, va.w * os);
-            *reinterpret_cast<float4*>(op_ + 4) = make_float4(vb.x * os, vb.y * os, vb.z * os, vb.w * os);
+            if (p.relu) {
+                va.x = fmaxf(va.x, 0.f); va.y = fmaxf(va.y, 0.f); va.z = fmaxf(va.z, 0.f); va.w = fmaxf(va.w, 0.f);
+                vb.x = fmaxf(vb.x, 0.f); vb.y = fmaxf(vb.y, 0.f); vb.z = fmaxf(vb.z, 0.f); vb.w = fmaxf(vb.w, 0.f);
+            }
+            float* op_ = orow + (size_t)x * p.out_cs + c;
+            if (p.out_h2) {
+                uint2 ha, la, hb, lb;
+                h2_pack(va, 1.f, ha, la, sat_mx);
+                h2_pack(vb, 1.f, hb, lb, sat_mx);
+                *reinterpret_cast<uint4*>(op_) = make_uint4(ha.x, ha.y, hb.x, hb.y);
+                *reinterpret_cast<uint4*>(op_ + 4) = make_uint4(la.x, la.y, lb.x, lb.y);
+            } else {
+                const float os = scaled ? p.inv_act_scale : 1.f;
+                *reinterpret_cast<float4*>(op_) = make_float4(va.x * os, va.y * os, va.z * os, va.w * os);
+                *reinterpret_cast<float4*>(op_ + 4) = make_float4(vb.x * os, vb.y * os, vb.z * os, vb.w * os);
+            }
         }
     }
     if (p.out_h2) sat_report(p.sat, sat_mx);
@@ -468,10 +481,17 @@ int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H,
     ROMP_REQUIRE(!p.out_h2 || ((out_cstride | out_coff) & 7) == 0, "fusesum: H2 output needs octet-aligned channels");
     p.act_scale = ldexpf(1.f, act_shift); p.inv_act_scale = ldexpf(1.f, -act_shift);
     p.sat = conv_sat_counter();
-    p.total = (size_t)B * H * W * p.C8;
-    size_t blocks = (p.total + 255) / 256;
+    p.rows_total = B * H;
+    const bool pow2 = (p.C8 & (p.C8 - 1)) == 0 && (W & (W - 1)) == 0;
+    p.c8_shift = 0;
+    while ((1 << p.c8_shift) < p.C8) ++p.c8_shift;
+    // rows of fewer than 256 (pixel, octet) units: smaller workgroups, so that no thread idles; every CU gets several workgroups
+    const int per_row = W * p.C8;
+    const int threads = per_row >= 256 ? 256 : (per_row >= 128 ? 128 : 64);
+    int blocks = p.rows_total;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(fusesum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (pow2) hipLaunchKernelGGL(fusesum_kernel<1>, dim3((unsigned)blocks), dim3(threads), 0, st, p);
+    else hipLaunchKernelGGL(fusesum_kernel<0>, dim3((unsigned)blocks), dim3(threads), 0, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

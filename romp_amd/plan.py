@@ -728,10 +728,25 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
                     q = f'{prefix}fuse_layers.{i}.{br}.'
                     first[(i, br)] = cbr(f'{q}0', xs[br], f'{q}0.0', f'{q}0.1', 3, 2, i - br != 1)
                     temps.append(first[(i, br)])
-            for i in range(min(br, n_out)):                      # 1x1 conv + BN towards output i < br; the upsample is folded into fusesum
-                q = f'{prefix}fuse_layers.{i}.{br}.'
-                ups[(i, br)] = cbr(q + 'up', xs[br], q + '0', q + '1', 1, 1, False)
-                temps.append(ups[(i, br)])
+            ups_to = list(range(min(br, n_out)))                 # 1x1 conv + BN towards every output i < br; the upsample is folded into fusesum
+            if len(ups_to) > 1 and merge_s2:                     # the same merge for the up-convs: one launch, xs[br] read once
+                ws, ss, bs = [], [], []
+                for i in ups_to:
+                    q = f'{prefix}fuse_layers.{i}.{br}.'
+                    w = sd[q + '0.weight']
+                    sc, sh = fold_bn(sd, q + '1', w.shape[0], sd.get(q + '0.bias'))
+                    ws.append(w); ss.append(sc); bs.append(sh)
+                m = P.conv(f'{prefix}fuse_layers.{ups_to[0]}-{ups_to[-1]}.{br}.up', xs[br], [torch.cat(ws, 0)], [torch.cat(ss)], [torch.cat(bs)], 1, 1, False)
+                temps.append(m)
+                off = 0
+                for i, w in zip(ups_to, ws):
+                    ups[(i, br)] = Act(m.buf, w.shape[0], m.H, m.W, m.cstride, m.coff + off)
+                    off += w.shape[0]
+            else:
+                for i in ups_to:
+                    q = f'{prefix}fuse_layers.{i}.{br}.'
+                    ups[(i, br)] = cbr(q + 'up', xs[br], q + '0', q + '1', 1, 1, False)
+                    temps.append(ups[(i, br)])
         P.join()
         outs = []
         P.fork(n_out - 1)

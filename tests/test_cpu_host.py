@@ -130,7 +130,10 @@ def test_program_matches_reference_inventory(program):
     # round 4: the sibling stride-2 convs of a fuse layer (same input, model.py:198-221) are ONE op named fuse_layers.<i0>-<i1>.<j>.0
     merged = [re.search(r'fuse_layers\.(\d+)-(\d+)\.', n) for n in program.names]
     siblings = sum(int(m.group(2)) - int(m.group(1)) for m in merged if m)
-    assert siblings == 4 * 1 + 2 * (2 + 1) and all(o.relu_from in (64, 128) for o, m in zip(program.ops, merged) if m)
+    # stride-2 firsts: 4 stage-3 modules x 1 + 2 stage-4 modules x (2 + 1); 1x1 up-convs sharing a source: 4 x 1 + 3 x (1 + 2), the
+    # last stage-4 module has output 0 only (nothing to merge)
+    assert siblings == 4 * 1 + 2 * (2 + 1) + 4 * 1 + 2 * (1 + 2), siblings
+    assert all(o.relu_from in (64, 128) for o, m, n in zip(program.ops, merged, program.names) if m and not n.endswith('.up'))
     n_conv_ref = sum(o.groups for o in program.ops if o.kind == OP_CONV) + 2 + 1 + siblings   # +2 merged head convs, +1 stem
     assert n_conv_ref == 310
     gflop = sum(program.flops) / 1e9
@@ -430,7 +433,7 @@ def test_export_cli_bev_host_tables(tmp_path):
     from romp_amd.bev_plan import cam3dmap_anchor
     assert np.allclose(anchors, cam3dmap_anchor(60, 128))
     dev_ops = [o for o in plan['ops'] if o.weight and not (o.weight & export.HOST_BIT)]
-    assert len(dev_ops) > 290
+    assert len(dev_ops) > 270
 
 
 def test_pack_h2_wave16_is_the_documented_permutation():
