@@ -29,7 +29,11 @@
 
 namespace romp {
 
-template <int P, int NS, int TW>
+// KSUB (round 4): 16-channel SUB-stages per barrier interval.  KSUB = 2 ("ck32"): a stage is 32 input channels = two sub-stage
+// buffers side by side, the weights of sub-stage 1 re-loaded tap by tap under sub-stage 0 (still 72 registers), ONE barrier and one
+// full memory drain per 32 channels instead of two -- the stage skeleton (drain + barrier + prefetch set-up) was ~1 000 of a stage's
+// ~5 500 cycles in the phase traces.
+template <int P, int NS, int TW, int KSUB = 1>
 struct RCfg {
     static constexpr int NWV = 4, CK = 16;
     static constexpr int PG = NWV / NS;                        // pixel groups (waves along the pixel dimension)
@@ -39,15 +43,20 @@ struct RCfg {
     static constexpr int NI = ((C::HR * RSU + 63) / 64 + NWV - 1) / NWV;   // DMA pieces (wave-instructions of 1 KiB) per wave and stage
     static constexpr int NA_I = NI * NWV;                      // ... per stage: piece k of wave w is instruction k * 4 + w; units past
                                                                // the haloed tile are zero-filled padding (no "is there a piece" branch)
-    static constexpr int STAGE_BYTES = NA_I * 1024;
+    static constexpr int SUB_BYTES = NA_I * 1024;              // one 16-channel sub-stage
+    static constexpr int STAGE_BYTES = KSUB * SUB_BYTES;
     static constexpr int SS_BYTES = NS * 256;                  // per slot: [slice][scale 32 | shift 32] floats
-    static constexpr int OFF_E = 2 * STAGE_BYTES;              // epilogue staging tiles, one per wave
-    static constexpr int OFF_S = OFF_E + NWV * EPI_WAVE;
+    // epilogue staging tiles of the LDS-transposed epilogue (float32 outputs; H2 outputs take the direct one), one per wave: in the
+    // stage buffer the item has just consumed when that is big enough (after a barrier: every wave done reading it), else a region
+    // of their own
+    static constexpr bool EPI_ALIAS = STAGE_BYTES >= NWV * EPI_WAVE;
+    static constexpr int OFF_E = 2 * STAGE_BYTES;
+    static constexpr int OFF_S = OFF_E + (EPI_ALIAS ? 0 : NWV * EPI_WAVE);
     static constexpr int LDS_BYTES = OFF_S + 2 * SS_BYTES + 16;
     static constexpr int G = P >= 2 ? 2 : 1;                   // blocks per unit: a unit = 2G fragment reads + 3G MFMAs (accumulators alternate)
     static constexpr int PFU = 2;                              // fragment reads run PFU units ahead of their MFMAs
     static_assert(NS == 1 || NS == 2 || NS == 4, "channel slices per workgroup");
-    static_assert(NI <= 9, "at most one DMA piece per tap");
+    static_assert(KSUB * NI <= KSUB * 9, "at most one DMA piece per tap end");
     static_assert((C::HR - 1) * RSU * 16 + RSU * 16 < 65536, "fragment read offsets are ds_read immediates");
 };
 
@@ -61,10 +70,10 @@ struct RStage {                 // wave-uniform description of one stage's sourc
     int c0;
 };
 
-template <int P, int NS, int TW>
+template <int P, int NS, int TW, int KSUB = 1>
 __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
     if (p.dbg & 32) return;                            // ablation: launch cost only
-    using X = RCfg<P, NS, TW>;
+    using X = RCfg<P, NS, TW, KSUB>;
     using C = typename X::C;
     using frag = f16x8;
     constexpr int NWV = X::NWV, PG = X::PG, G = X::G, PFU = X::PFU;
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
     const int sl = wave % NS, pg = wave / NS;                  // channel slice, pixel group
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
-    const int n_chunks = p.cin_pad >> 4;
+    const int n_chunks = (p.cin_pad >> 4) / KSUB;              // stages: KSUB x 16 input channels each
     const int cin16 = p.cin_pad >> 4;
     char* sE = sBuf + X::OFF_E + wave * EPI_WAVE;
 
@@ -109,17 +118,18 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
         d.c0 = c0;
         return d;
     };
-    auto issue_piece = [&](int k, const RStage& d, int buf) {
+    auto issue_piece = [&](int ks, const RStage& d, int buf) {             // piece ks = sub-stage ks / NI, piece ks % NI of it
+        const int sub = ks / X::NI, k = ks % X::NI;
         const int i = k * NWV + wave;                                      // wave-uniform
         int rc = d_rc[k];
         asm volatile("" : "+v"(rc));                                       // (opaque: keeps the per-piece address parts from being hoisted into VGPRs)
         const int row = rc & 255, col = (rc >> 8) & 255, w = (rc >> 17) & 3;
         const int iy = d.iy0 + row, ix = d.ix0 + col;
         const int ok = ((rc >> 16) & 1) & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) &
-                       (int)(d.c0 + (w >> 1) * 8 < p.cin_valid) & cold;
-        const unsigned long long a_in = (unsigned long long)(d.in + ((iy * p.W + ix) * p.in_cs + w * 4));
+                       (int)(d.c0 + sub * 16 + (w >> 1) * 8 < p.cin_valid) & cold;
+        const unsigned long long a_in = (unsigned long long)(d.in + ((iy * p.W + ix) * p.in_cs + sub * 16 + w * 4));
         const unsigned long long a = ok ? a_in : (unsigned long long)p.zero;
-        __builtin_amdgcn_global_load_lds((glb_void_r*)a, (lds_void_r*)(sBuf + buf * X::STAGE_BYTES + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_r*)a, (lds_void_r*)(sBuf + buf * X::STAGE_BYTES + sub * X::SUB_BYTES + i * 1024), 16, 0, 0);
     };
     // scale | shift of an item: wave s < NS fetches slice s, one dword per lane
     auto issue_ss = [&](const Item& it, int slot) {
@@ -155,12 +165,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
     constexpr int tr_wpw = NWV;
     ROMP_TRACE(1);
     Item cur = decode_item(p, q, j_cur0, C::NW);
+    const uint4* cwg;                                          // weights of the stage being computed (sub-stage 0)
     {
         const RStage d0 = make_desc(cur, 0);
 #pragma unroll
-        for (int k = 0; k < X::NI; ++k) issue_piece(k, d0, 0);
+        for (int k = 0; k < KSUB * X::NI; ++k) issue_piece(k, d0, 0);
         issue_ss(cur, 0);
         const uint4* wp0 = d0.wg + w_lane;
+        cwg = d0.wg;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) load_w(wp0, tap);
     }
@@ -185,30 +197,33 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
     while (true) {
         const bool last = ch + 1 == n_chunks;
         // the stage to prefetch; a workgroup's final stage re-fetches itself (harmless, keeps the stage body branch-free)
-        const RStage nd = make_desc(last ? (have_next ? nxt : cur) : cur, last ? (have_next ? 0 : ch * 16) : (ch + 1) * 16);
+        const RStage nd = make_desc(last ? (have_next ? nxt : cur) : cur, last ? (have_next ? 0 : ch * 16 * KSUB) : (ch + 1) * 16 * KSUB);
         const int nbuf = buf ^ 1;
         ROMP_TRACE(10);
         if (!(p.dbg & 8)) {
             const char* sA = sBuf + buf * X::STAGE_BYTES;
-            constexpr int UPT = P / G, NUNIT = 9 * UPT;            // units per tap, per stage
+            constexpr int UPT = P / G, NUSUB = 9 * UPT, NUNIT = KSUB * NUSUB;   // units per tap, per sub-stage, per stage
             frag xf[PFU + 1][G][2];
             auto read_x = [&](int u) {
-                const int tap = u / UPT, j0 = (u % UPT) * G;
+                const int sub = u / NUSUB, tap = (u % NUSUB) / UPT, j0 = (u % UPT) * G;
                 const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
                 for (int g = 0; g < G; ++g)
 #pragma unroll
                     for (int pc = 0; pc < 2; ++pc)
                         xf[u % (PFU + 1)][g][pc] =
-                            *reinterpret_cast<const frag*>(sA + xa[dx][pc] + ((j0 + g) * C::RPB + dy) * (X::RSU * 16));
+                            *reinterpret_cast<const frag*>(sA + sub * X::SUB_BYTES + xa[dx][pc] + ((j0 + g) * C::RPB + dy) * (X::RSU * 16));
             };
-            const uint4* wp = nd.wg + w_lane;
+            // a tap's registers are re-loaded right after its last MFMA of a sub-stage: with the weights of the NEXT sub-stage (the
+            // same stage's second 16 channels: one chunk = 4 * cout_pad units further on), or of the next stage's first
+            const uint4* wp = (KSUB == 2 ? cwg + 4 * p.cout_pad : nd.wg) + w_lane;
+            const uint4* wp2 = nd.wg + w_lane;
 #pragma unroll
             for (int u = 0; u < PFU; ++u) read_x(u);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < NUNIT; ++u) {
-                const int tap = u / UPT, j0 = (u % UPT) * G;
+                const int sub = u / NUSUB, tap = (u % NUSUB) / UPT, j0 = (u % UPT) * G;
                 if (u + PFU < NUNIT) read_x(u + PFU);
                 const frag (&x)[G][2] = xf[u % (PFU + 1)];
                 // h1w2 + h2w1 + h1w1 (smallest terms first), product-major so that consecutive MFMAs hit different accumulators
@@ -219,20 +234,22 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[j0 + g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap][0], x[g][0], acc[j0 + g][0], 0, 0, 0);
                 const bool tap_end = u % UPT == UPT - 1;
-                if (tap_end) {                                     // tap done: its registers take the next stage's weights
-                    load_w(wp, tap);
-                    if (tap < X::NI) issue_piece(tap, nd, nbuf);
+                const int te = sub * 9 + tap;                      // tap end number of the stage: DMA piece `te` of the next stage rides along
+                if (tap_end) {                                     // tap done: its registers take the next sub-stage's weights
+                    if (KSUB == 2 && sub == 1) load_w(wp2, tap); else load_w(wp, tap);
+                    if (te < KSUB * X::NI) issue_piece(te, nd, nbuf);
                 }
                 // the order inside the unit: its look-ahead reads, its MFMAs, the memory issues of a tap end; units stay in order
                 if (u + PFU < NUNIT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * G, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);
                 if (tap_end) {
-                    if (tap < X::NI) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
+                    if (te < KSUB * X::NI) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        cwg = nd.wg;
         ROMP_TRACE(11);
         if (last) {
             if (have_next) issue_ss(nxt, slot ^ 1);
@@ -246,7 +263,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
                 const float* sc_e = reinterpret_cast<const float*>(sSb + slot * X::SS_BYTES) + sl * 64;
                 // H2 out (+ H2 residual): the direct epilogue (conv_common.h; ROMP_CONV_DEBUG=512 keeps the LDS-transposed one: A/B runs)
                 if (p.out_h2 && p.vec_io && (!p.res || p.res_h2) && !(p.dbg & 512)) conv_epilogue_h2direct<3, 1, P, TW, PG>(p, ce, acc, sc_e, pg, lane_e & 31, lane_e >> 5);
-                else conv_epilogue<3, 1, P, 1, TW, 16, PG>(p, ce, acc, sc_e, sE, pg, lane_e & 31, lane_e >> 5);
+                else {
+                    char* se = sE;
+                    if (X::EPI_ALIAS) {                            // (a workgroup-uniform branch: every wave meets at this barrier)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        se = sBuf + buf * X::STAGE_BYTES + wave * EPI_WAVE;
+                    }
+                    conv_epilogue<3, 1, P, 1, TW, 16, PG>(p, ce, acc, sc_e, se, pg, lane_e & 31, lane_e >> 5);
+                }
             }
 #pragma unroll
             for (int j = 0; j < P; ++j)
@@ -278,10 +303,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
 #define ROMP_CONV_VARIANT_H2R(P, NS, TW)                                                               \
     { 3, 1, P, NS, TW, 16, conv_h2r_kernel<P, NS, TW>, RCfg<P, NS, TW>::LDS_BYTES,                     \
       RCfg<P, NS, TW>::C::TH, 0, 0, 8, 256 }
+#define ROMP_CONV_VARIANT_H2R32(P, NS, TW)                                                             \
+    { 3, 1, P, NS, TW, 32, conv_h2r_kernel<P, NS, TW, 2>, RCfg<P, NS, TW, 2>::LDS_BYTES,               \
+      RCfg<P, NS, TW, 2>::C::TH, 0, 0, 8, 256 }
 
 static ConvVariant kVariantsH2r[] = {
     ROMP_CONV_VARIANT_H2R(2, 1, 16), ROMP_CONV_VARIANT_H2R(2, 2, 16), ROMP_CONV_VARIANT_H2R(2, 4, 16), ROMP_CONV_VARIANT_H2R(1, 4, 16),
     ROMP_CONV_VARIANT_H2R(2, 1, 32), ROMP_CONV_VARIANT_H2R(2, 2, 32), ROMP_CONV_VARIANT_H2R(1, 1, 16),
+    ROMP_CONV_VARIANT_H2R32(2, 4, 16), ROMP_CONV_VARIANT_H2R32(2, 2, 16), ROMP_CONV_VARIANT_H2R32(2, 2, 32), ROMP_CONV_VARIANT_H2R32(2, 1, 16),
     // (round 4, measured and dropped: P = 4 -- four pixel blocks per wave, the same 72 weight registers per stage feeding twice the
     // MFMAs, one workgroup per CU with up to 512 registers: 42.6 vs 41.3 us on 128 -> 128 @32^2, 51.5 vs 43.2 us on 64 -> 64 @64^2;
     // the in-order wave alone on its SIMD hides less of its own latencies than two half-size ones: profiles/r04_s2_notes.md)
