@@ -38,7 +38,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf
 BX3_PRODUCTS = 6                  # bf16 piece products issued per f32 product by the bf16x3 kernels
 H2_PRODUCTS = 3                   # fp16 piece products issued per f32 product by the f16x2 kernels
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = 'r03'               # profiles/<tag>_pmc_traffic_by_op.json: the committed rocprofv3 PMC passes of this build
+PROFILE_TAG = 'r04'               # profiles/<tag>_pmc_traffic_by_op.json: the committed rocprofv3 PMC passes of this build
 
 
 def parse_args():
@@ -392,16 +392,30 @@ def bench_smpl(args, dev):
                         'alg_bytes_per_launch': base_bytes + out_bytes, 'gflops_per_launch': round(flops / 1e9, 3),
                         'note': 'the SMPL kernels of one call (pose, skin, joints); latency bound at N=64'}}
     if not args.no_cpu_baseline:
-        from oracle import romp_oracle as O
+        from oracle import romp_oracle as O, ref_cpu
         torch.set_num_threads(usable_cores())
         bn, pn = betas.cpu().numpy(), poses.cpu().numpy()
         vo, jo, _ = O.smpl_forward(model, bn, pn)
-        t0, n = time.time(), 0
-        while time.time() - t0 < min(args.cpu_seconds, 10.0) and n < 200:
-            O.smpl_forward(model, bn, pn); n += 1
-        cdt = time.time() - t0
-        res['cpu_baseline'] = dict(value=round(N * n / cdt, 1), unit='meshes/s', cores=torch.get_num_threads(), kind='port',
-                                   sample='%d calls of the torch-CPU restatement of smpl.py lbs at N=64' % n)
+        if ref_cpu.available():          # the reference's own SMPL module (oracle/_ref/romp/smpl.pyc: simple_romp/romp/smpl.py:62-108), PyTorch-CPU
+            ref_smpl = ref_cpu.reference_smpl(model)
+            bc, pc = betas.cpu(), poses.cpu()
+            with torch.no_grad():
+                vr = ref_smpl(bc, pc)[0]
+                t0, n = time.time(), 0
+                while time.time() - t0 < min(args.cpu_seconds, 10.0) and n < 200:
+                    ref_smpl(bc, pc); n += 1
+            cdt = time.time() - t0
+            res['cpu_baseline'] = dict(value=round(N * n / cdt, 1), unit='meshes/s', cores=torch.get_num_threads(), kind='reference',
+                                       sample='%d calls of the reference\'s SMPL.forward (simple_romp/romp/smpl.py:62-108, byte-compiled from '
+                                              '/root/reference into oracle/_ref/romp) at N=64, PyTorch-CPU float32' % n)
+            res['config']['verts_max_abs_vs_reference'] = float((v.cpu() - vr).abs().max())
+        else:
+            t0, n = time.time(), 0
+            while time.time() - t0 < min(args.cpu_seconds, 10.0) and n < 200:
+                O.smpl_forward(model, bn, pn); n += 1
+            cdt = time.time() - t0
+            res['cpu_baseline'] = dict(value=round(N * n / cdt, 1), unit='meshes/s', cores=torch.get_num_threads(), kind='port',
+                                       sample='%d calls of the torch-CPU restatement of smpl.py lbs at N=64' % n)
         res['config']['verts_max_abs_vs_oracle'] = float(np.abs(v.cpu().numpy() - vo).max())
     print(json.dumps(res), flush=True)
 
@@ -676,7 +690,8 @@ def main():
                       open(args.dump_op_kernels, 'w'))
         if not args.no_roofline:
             with torch.cuda.stream(stream):
-                roof, classes = roofline_report(model.model, first, pmc_workload=(None if B != 32 else '' if args.backbone == 'hrnet32' else '_' + args.backbone))
+                roof, classes = roofline_report(model.model, first, pmc_workload=(('' if B == 32 else '_b%d' % B) if args.backbone == 'hrnet32' else
+                                                                                  ('_' + args.backbone if B == 32 else None)))
             result['roofline'] = roof
             result['kernel_classes'] = classes
         if not args.no_parity:

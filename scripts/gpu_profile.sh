@@ -4,7 +4,7 @@
 # The profiled command is bench.py's default workload cut to 2 forward calls of 32 images per step (--global-batch 64): the
 # same kernels and variant table as the 1024-image job, a trace of a manageable size.
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
-OUT="$REPO/gpurun_out/prof"
+OUT="$REPO/gpurun_out/prof${PROF_TAG}"                # PROF_TAG: e.g. _bev, _resnet50, _b128 for the secondary workloads' passes
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export PYTHONUNBUFFERED=1

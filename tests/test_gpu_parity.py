@@ -417,19 +417,26 @@ def test_fusesum_formats(dev):
     # run through a two-op program: the fuse sum is reachable through the network executor only
     from romp_amd.plan import Program, Act
     from romp_amd.lib import RompOp, OP_FUSESUM, BUF_NONE
-    for fmts, ofmt in (((0, 0, 0), 0), ((1, 1, 1), 1), ((1, 0, 1), 0), ((0, 1, 0), 1)):
+    # (last configuration: term 1 is a channel SLICE of a wider tensor -- a merged sibling conv's output, romp_op.term_coff)
+    for fmts, ofmt, coff1 in (((0, 0, 0), 0, 0), ((1, 1, 1), 1, 0), ((1, 0, 1), 0, 0), ((0, 1, 0), 1, 0), ((1, 1, 1), 1, 32), ((0, 0, 1), 0, 64)):
         op = RompOp()
         op.kind, op.in_buf, op.res_buf, op.out_buf = OP_FUSESUM, BUF_NONE, BUF_NONE, 3
         op.H, op.W, op.Cin, op.Cout, op.relu, op.n_terms = Hh, Hh, Cc, Cc, 1, 3
         op.out_cstride, op.out_fmt, op.act_shift = Cc, ofmt, 4
+        wide = Cc + 96 if coff1 else Cc                      # channel stride of term 1's buffer
         for k in range(3):
             op.term_buf[k], op.term_shift[k], op.term_cstride[k], op.term_fmt[k] = k, k, Cc, fmts[k]
-        sizes = [Hh * Hh * Cc, Hh * Hh * Cc // 4, Hh * Hh * Cc // 16, Hh * Hh * Cc]
+        op.term_cstride[1], op.term_coff[1] = wide, coff1
+        sizes = [Hh * Hh * Cc, Hh * Hh * wide // 4, Hh * Hh * Cc // 16, Hh * Hh * Cc]
         h = C.c_void_p()
         arr = (RompOp * 1)(op)
         L.check(lib.romp_net_create(C.byref(h), arr, 1, (C.c_int64 * 4)(*sizes), 4, B))
         try:
             for k, t in enumerate((t0, t1, t2)):
+                if k == 1 and coff1:                         # embed the term in a wider tensor of other data
+                    w_ = torch.randn(B, Hh // 2, Hh // 2, wide, generator=g) * 7.0
+                    w_[..., coff1:coff1 + Cc] = t
+                    t = w_
                 td = (encode_h2(t) if fmts[k] else t).to(dev).contiguous()
                 L.check(lib.romp_net_write_buffer(h, k, L.ptr(td), td.numel(), L.stream_ptr(dev)))
             dummy = torch.zeros(B * 16, device=dev)
