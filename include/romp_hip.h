@@ -88,6 +88,12 @@ const char* romp_last_error(void);
                                    plan.fuse_bottleneck_seams): the op before it (NOP) is a
                                    64->256 conv + residual + ReLU, this op the 256->64 conv + ReLU reading its output; both
                                    outputs are written; weight_aux = per-group packs                                            */
+#define ROMP_OP_FUSEUP    16    /* a fuse-layer output with its 1x1 up-convs inside (csrc/conv_fup.hip, plan.fuse_up_sums; model.py:186-196,233-244):
+                                   y = relu(sum of the terms), terms in op order: first the tensors already at the output's resolution
+                                   (term_shift 0), then for term_shift s = 1, 2, ..: nearest_up_2^s(bn(W_s . x_s)) where term_buf is the
+                                   SOURCE x_s (Cout << s dense channels at 1 / 2^s resolution).  weight_aux: the f16x2 weights W_s, each
+                                   repacked per 16-channel group (plan.pack_h2_wave16), concatenated; scale_h2 / shift: [s][Cout].
+                                   H2 tensors throughout; Cout 32 | 64 | 128; H x W = the OUTPUT size                            */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 /* romp_op.flags */

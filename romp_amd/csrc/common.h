@@ -57,6 +57,8 @@ struct FuseTerm { const float* ptr; int shift; int cstride; int fmt; };
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
                    int out_cstride, int out_coff, int relu, hipStream_t st, int out_fmt = 0, int act_shift = 0);
 
+int launch_fuseup(const romp_op& op, const FuseTerm* terms, float* out, int B, hipStream_t st);      // conv_fup.hip (terms == nullptr: set-up only)
+
 int launch_ksum(const romp_op& op, const float* partial, const float* res, float* out, int B, hipStream_t st);
 
 // BEV head pieces (bev.hip); *_host pointers are dereferenced on the host at launch time

@@ -166,6 +166,19 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(out, "fusesum: bad out buffer %d", op.out_buf);
             return launch_fusesum(t, op.n_terms, out, B, op.H, op.W, op.Cout, op.out_cstride, op.out_coff, op.relu, st, op.out_fmt, op.act_shift);
         }
+        case ROMP_OP_FUSEUP: {
+            FuseTerm t[4];
+            ROMP_REQUIRE(op.n_terms >= 2 && op.n_terms <= 4, "fuseup: n_terms %d", op.n_terms);
+            for (int k = 0; k < op.n_terms; ++k) {
+                t[k].ptr = resolve_in(n, op.term_buf[k], image);
+                ROMP_REQUIRE(t[k].ptr && op.term_coff[k] >= 0, "fuseup: bad term buffer %d", op.term_buf[k]);
+                t[k].ptr += op.term_coff[k];
+                t[k].shift = op.term_shift[k]; t[k].cstride = op.term_cstride[k]; t[k].fmt = op.term_fmt[k];
+            }
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(out, "fuseup: bad out buffer %d", op.out_buf);
+            return launch_fuseup(op, t, out, B, st);
+        }
         case ROMP_OP_KSUM: {
             const float* part = resolve_in(n, op.in_buf, image);
             const float* res = op.res_buf == ROMP_BUF_NONE ? nullptr : resolve_in(n, op.res_buf, image);
@@ -312,6 +325,11 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
             if (rc) return rc;
             break;
         }
+    for (int i = 0; i < n_ops; ++i)                            // (every instantiation in use: cheap, idempotent)
+        if (ops_host[i].kind == ROMP_OP_FUSEUP) {
+            const int rc = launch_fuseup(ops_host[i], nullptr, nullptr, 0, nullptr);
+            if (rc) return rc;
+        }
     for (int i = 0, seen = 0; i < n_ops && seen != 3; ++i) {  // the fused blocks' one-time set-up (hipMalloc / attributes) must not run inside a stream capture
         const int kind = ops_host[i].kind;
         if (kind == ROMP_OP_BBLOCK32 && !(seen & 1) && i > 0) {
@@ -334,7 +352,7 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
     for (int i = 1; i < n_ops && n->image_only_in_op0; ++i) {
         const romp_op& o = n->ops[i];
         bool reads = o.in_buf == ROMP_BUF_IMAGE || o.res_buf == ROMP_BUF_IMAGE;
-        for (int k = 0; k < 4; ++k) reads |= (o.kind == ROMP_OP_FUSESUM && k < o.n_terms && o.term_buf[k] == ROMP_BUF_IMAGE);
+        for (int k = 0; k < 4; ++k) reads |= ((o.kind == ROMP_OP_FUSESUM || o.kind == ROMP_OP_FUSEUP) && k < o.n_terms && o.term_buf[k] == ROMP_BUF_IMAGE);
         if (reads) n->image_only_in_op0 = false;
     }
     n->bufs.resize(n_bufs, nullptr);
@@ -637,7 +655,7 @@ static bool op_out_region(const romp_op& op, long long* npix, int* cs, int* coff
             *C = op.groups > 1 ? (op.groups - 1) * op.out_gstride + op.Cout : op.Cout;
             break; }
         case ROMP_OP_STEM: case ROMP_OP_STEM7: Ho = op.H / 2; Wo = op.W / 2; *C = op.Cout; break;
-        case ROMP_OP_FUSESUM: case ROMP_OP_KSUM: case ROMP_OP_BBLOCK32: case ROMP_OP_BBLOCK64: case ROMP_OP_SEAM1X1: *C = op.Cout; break;
+        case ROMP_OP_FUSESUM: case ROMP_OP_FUSEUP: case ROMP_OP_KSUM: case ROMP_OP_BBLOCK32: case ROMP_OP_BBLOCK64: case ROMP_OP_SEAM1X1: *C = op.Cout; break;
         default: return false;
     }
     *npix = (long long)Ho * Wo; *cs = op.out_cstride; *coff = op.out_coff;
@@ -779,6 +797,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     ROMP_REQUIRE(op && out && n > 0 && B > 0, "romp_conv_describe: bad arguments");
     if (op->kind == ROMP_OP_STEM) { snprintf(out, n, "stem_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FUSESUM) { snprintf(out, n, "fusesum"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_FUSEUP) { snprintf(out, n, "fuseup"); return ROMP_OK; }
     if (op->kind == ROMP_OP_KSUM) { snprintf(out, n, "ksum"); return ROMP_OK; }
     if (op->kind == ROMP_OP_STEM7) { snprintf(out, n, "stem7_conv"); return ROMP_OK; }
     if (op->kind == ROMP_OP_MAXPOOL) { snprintf(out, n, "maxpool3s2"); return ROMP_OK; }

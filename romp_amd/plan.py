@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OPF_WAVE16, OPF_STEM_VALU, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OPF_WAVE16, OPF_STEM_VALU, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -321,6 +321,85 @@ def fuse_bottleneck_seams(P):
         P.bytes[i] = 0.0
         P.fused_seams += 1
     return P.fused_seams
+
+
+FUP_TILE = {32: (8, 64), 64: (8, 32), 128: (4, 32)}          # csrc/conv_fup.hip: output tile (rows, columns) by channel count
+
+
+def fuse_up_sums(P):
+    """Peephole (after assign_formats; csrc/conv_fup.hip, ROMP_OP_FUSEUP): a fuse-layer output whose up-terms are 1x1 convs of the
+    lower-resolution branch outputs (model.py:186-196,233-244) computes them itself: the FUSESUM turns into FUSEUP with the convs'
+    SOURCES as its up-terms and their weights (the slice of a merged conv that belongs to this output, repacked per 16-channel
+    group) attached; a 1x1 conv all of whose consumers were fused turns into ROMP_OP_NOP.  H2 tensors throughout; HRNet's shapes
+    (Cout 32 / 64 / 128, source k of Cout << k channels at 1 / 2^k resolution).  Env ROMP_FUSEUP=0: off.  -> number of fused outputs."""
+    import os
+    P.fused_ups = 0
+    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSEUP', '1') == '0':
+        return 0
+    by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
+    consumed = {}                                             # conv op index -> [fusesum op indices that took a slice of it]
+    for fi, F in enumerate(P.ops):
+        if F.kind != OP_FUSESUM or F.out_fmt != FMT_H2 or F.Cout not in FUP_TILE or F.n_terms < 2:
+            continue
+        th, tw = FUP_TILE[F.Cout]
+        shifts = [F.term_shift[k] for k in range(F.n_terms)]
+        n_dir = sum(1 for s in shifts if s == 0)
+        ups = shifts[n_dir:]
+        if not (1 <= n_dir <= 3 and ups and shifts[:n_dir] == [0] * n_dir and ups == list(range(1, len(ups) + 1)) and
+                F.H % th == 0 and F.W % tw == 0 and all(F.term_fmt[k] == FMT_H2 for k in range(F.n_terms)) and (th >> len(ups)) >= 1):
+            continue
+        prods = []
+        for u, k in enumerate(range(n_dir, F.n_terms)):
+            # the conv that wrote this term: the last writer of the buffer before the sum, covering the term's channel slice
+            cand = [j for j in range(fi) if P.ops[j].kind == OP_CONV and P.ops[j].out_buf == F.term_buf[k]]
+            U = P.ops[cand[-1]] if cand else None
+            c0 = F.term_coff[k] - (U.out_coff if U is not None else 0)
+            ok = (U is not None and U.ksize == 1 and U.stride == 1 and U.groups == 1 and not U.relu and U.res_buf < 0 and U.weight_h2 and U.scale_h2 and
+                  U.in_fmt == FMT_H2 and U.out_fmt == FMT_H2 and U.Cin == (F.Cout << (u + 1)) and U.cin_pad == U.Cin and U.in_cstride == U.Cin and
+                  U.in_coff == 0 and U.in_buf >= 0 and U.H == (F.H >> (u + 1)) and U.W == (F.W >> (u + 1)) and U.out_cstride == F.term_cstride[k] and
+                  0 <= c0 and c0 + F.Cout <= U.Cout and c0 % 16 == 0 and U.act_shift == F.act_shift and
+                  U.out_rstride == 0 and U.out_bstride == 0)
+            if not ok:
+                prods = None
+                break
+            prods.append((cand[-1], U, c0))
+        if not prods:
+            continue
+        packs, scs, shs = [], [], []
+        for j, U, c0 in prods:
+            w = by_ptr[U.weight_h2].view(1, U.Cin // 16, 2, 2, U.cout_pad, 8)[:, :, :, :, c0:c0 + F.Cout, :]
+            packs.append(pack_h2_wave16(w.contiguous()).reshape(-1))
+            scs.append(by_ptr[U.scale_h2].reshape(-1)[c0:c0 + F.Cout])
+            shs.append(by_ptr[U.shift].reshape(-1)[c0:c0 + F.Cout])
+        pw, ps, pb = torch.cat(packs).contiguous(), torch.stack(scs).contiguous(), torch.stack(shs).contiguous()
+        P.consts += [pw, ps, pb]
+        F.kind = OP_FUSEUP
+        F.weight_aux, F.scale_h2, F.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+        F.flags |= OPF_WAVE16
+        up_bytes = 0.0
+        for (j, U, c0), k in zip(prods, range(n_dir, F.n_terms)):
+            # the term is now the conv's SOURCE; account the conv's share of flops / bytes to this op
+            P.bytes[fi] += 4.0 * U.H * U.W * (U.Cin - F.Cout)          # reads x_s instead of the small term
+            P.flops[fi] += 2.0 * U.H * U.W * U.Cin * F.Cout
+            F.term_buf[k], F.term_cstride[k], F.term_coff[k] = U.in_buf, U.in_cstride, 0
+            consumed.setdefault(j, []).append(fi)
+        P.fused_ups += 1
+    # a conv whose every reader was fused no longer runs
+    for j, fis in consumed.items():
+        U = P.ops[j]
+        readers = [i for i in range(j + 1, len(P.ops))
+                   if any(P.ops[i].kind in (OP_FUSESUM,) and P.ops[i].term_buf[k] == U.out_buf for k in range(P.ops[i].n_terms))
+                   or (P.ops[i].kind in (OP_CONV, OP_KSUM) and (P.ops[i].in_buf == U.out_buf or P.ops[i].res_buf == U.out_buf))]
+        # (readers of a LATER live range of the same arena buffer come after its next writer: stop there)
+        nxt = [i for i in range(j + 1, len(P.ops)) if P.ops[i].out_buf == U.out_buf and P.ops[i].kind not in (OP_NOP, OP_FORK, OP_JOIN)]
+        if nxt:
+            readers = [i for i in readers if i <= nxt[0]]
+        if not readers:
+            share = P.flops[j]
+            U.kind = OP_NOP
+            P.flops[j] = 0.0
+            P.bytes[j] = 0.0
+    return P.fused_ups
 
 
 def fuse_basic_blocks(P):
@@ -632,6 +711,7 @@ class Program:
             assign_formats(self)
             fuse_basic_blocks(self)
             fuse_bottleneck_seams(self)
+            fuse_up_sums(self)
             self._lowered = True
         arr = (RompOp * len(self.ops))()
         for i, o in enumerate(self.ops):

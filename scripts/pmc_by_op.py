@@ -15,7 +15,7 @@ import re
 import sys
 from collections import defaultdict
 
-NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|stem_conv_kernel|stem_mfma_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
+NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|fuseup_kernel|stem_conv_kernel|stem_mfma_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
 FIRST = ('stem_conv_kernel', 'stem_mfma_kernel', 'stem7_conv_kernel')
 
 
@@ -26,6 +26,8 @@ def kernel_of(variant_name):
         return ('bblockr_kernel<64',)
     if variant_name == 'seam1x1':
         return ('seam1x1_kernel',)
+    if variant_name == 'fuseup':
+        return ('fuseup_kernel',)
     m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2s|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None

@@ -399,6 +399,84 @@ def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
         lib.romp_net_destroy(h)
 
 
+@pytest.mark.parametrize('CO,NUP,ND,H,B', [(32, 1, 1, 64, 1), (32, 2, 1, 64, 3), (32, 3, 1, 128, 2), (64, 1, 2, 32, 3), (64, 2, 2, 64, 2), (128, 1, 3, 32, 3)])
+def test_fuseup(dev, CO, NUP, ND, H, B):
+    """csrc/conv_fup.hip (ROMP_OP_FUSEUP): a fuse-layer output with its 1x1 up-convs inside, lowered by plan.fuse_up_sums from the
+    ordinary [1x1 convs ..., fusesum] form -- here with the up-convs MERGED over two outputs like plan.hr_module emits them (the
+    output under test takes channel slice [16 : 16 + CO) of each) -- against torch: y = relu(sum of ND direct tensors +
+    sum_k up_{2^k}(bn_k(W_k x_k))), x_k with CO << k channels at 1 / 2^k of the resolution.  HRNet's production shapes and small ones,
+    B > 1, every instantiation of the kernel."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math, decode_h2
+    g = torch.Generator().manual_seed(CO + 10 * NUP + H)
+    cin0 = 32
+    img = torch.randn(B, H, H, cin0, generator=g)
+
+    def mk(co, ci, k):
+        return (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5, torch.rand(co, generator=g) + 0.5, torch.randn(co, generator=g) * 0.2)
+
+    def tconv(t, wsb, stride, relu):
+        w, sc, sh = wsb
+        y = F.conv2d(t, w, None, stride=stride, padding=w.shape[-1] // 2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        return torch.relu(y) if relu else y
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    x_img = Act(L.BUF_IMAGE, cin0, H, H, cin0)
+    xin = img.permute(0, 3, 1, 2)
+    # sources: x_0 (CO @ H, a direct term), x_k (CO << k @ H >> k): a chain of stride-2 convs; extra direct terms from x_0
+    srcs_w = [mk(CO, cin0, 3)] + [mk(CO << k, CO << (k - 1), 3) for k in range(1, NUP + 1)]
+    acts, refs = [], []
+    a, r = P.conv('x0', x_img, [srcs_w[0][0]], [srcs_w[0][1]], [srcs_w[0][2]], 3, 1, True), tconv(xin, srcs_w[0], 1, True)
+    acts.append(a); refs.append(r)
+    for k in range(1, NUP + 1):
+        a = P.conv('x%d' % k, acts[-1], [srcs_w[k][0]], [srcs_w[k][1]], [srcs_w[k][2]], 3, 2, True)
+        r = tconv(refs[-1], srcs_w[k], 2, True)
+        acts.append(a); refs.append(r)
+    directs, dref = [acts[0]], [refs[0]]
+    for d in range(1, ND):
+        wsb = mk(CO, CO, 1)
+        directs.append(P.conv('d%d' % d, acts[0], [wsb[0]], [wsb[1]], [wsb[2]], 1, 1, False))
+        dref.append(tconv(refs[0], wsb, 1, False))
+    ups, uref = [], []
+    for k in range(1, NUP + 1):                               # merged 1x1 conv: 16 other channels | CO channels of THIS output | 16 more
+        wsb = mk(CO + 32, CO << k, 1)
+        m = P.conv('up%d' % k, acts[k], [wsb[0]], [wsb[1]], [wsb[2]], 1, 1, False)
+        ups.append(Act(m.buf, CO, m.H, m.W, m.cstride, 16))
+        u = tconv(refs[k], wsb, 1, False)[:, 16:16 + CO]
+        uref.append(u.repeat_interleave(1 << k, 2).repeat_interleave(1 << k, 3))
+    out = P.fusesum('fuse', directs + ups, [0] * ND + list(range(1, NUP + 1)), True)
+    sink = P.conv('sink', out, [mk(32, CO, 1)[0]], [torch.ones(32)], [torch.zeros(32)], 1, 1, False)    # an H2 consumer: keeps `out` in the H2 format
+    ref = dref[0]
+    for t in dref[1:] + uref:
+        ref = ref + t
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    ops = P.op_array()
+    assert P.fused_ups == 1, 'plan.fuse_up_sums must fuse the output (kinds %s)' % [o.kind for o in P.ops]
+    fup = [o for o in P.ops if o.kind == L.OP_FUSEUP][0]
+    assert [o.kind for o in P.ops if o.kind == L.OP_FUSESUM] == [] and sum(o.kind == L.OP_NOP for o in P.ops) == NUP
+    assert fup.out_fmt == L.FMT_H2 and fup.n_terms == ND + NUP
+    lib = L.load()
+    h = C.c_void_p()
+    sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+    L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+    try:
+        xd = img.to(dev).contiguous()
+        dummy = torch.empty(16, device=dev)
+        n = P.buf_floats[out.buf] * B
+        got = torch.empty(n, device=dev)
+        for rep in range(2):
+            L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+            L.check(lib.romp_net_read_buffer(h, out.buf, B, L.ptr(got), n, L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            y = decode_h2(got.cpu().reshape(B, H, H, CO))
+            err = (y - ref).abs().max().item() / ref.abs().max().item()
+            print(f'fuseup CO={CO} NUP={NUP} ND={ND} B={B} {H}x{H} run {rep}: relative err {err:.3e}')
+            assert err < 5e-5, err
+    finally:
+        lib.romp_net_destroy(h)
+
+
 def test_fusesum_formats(dev):
     """The fuse sum (model.py:233-244) with float32 and H2 terms / outputs gives the same values (the power-of-two scaling of
     the H2 format commutes with every rounding of the sum)."""
