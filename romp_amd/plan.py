@@ -331,10 +331,14 @@ def fuse_up_sums(P):
     lower-resolution branch outputs (model.py:186-196,233-244) computes them itself: the FUSESUM turns into FUSEUP with the convs'
     SOURCES as its up-terms and their weights (the slice of a merged conv that belongs to this output, repacked per 16-channel
     group) attached; a 1x1 conv all of whose consumers were fused turns into ROMP_OP_NOP.  H2 tensors throughout; HRNet's shapes
-    (Cout 32 / 64 / 128, source k of Cout << k channels at 1 / 2^k resolution).  Env ROMP_FUSEUP=0: off.  -> number of fused outputs."""
+    (Cout 32 / 64 / 128, source k of Cout << k channels at 1 / 2^k resolution).  Batch plans only: a single image is 32 tiles of
+    this kernel, on the launch-bound chain that costs more than the small convs did (frame 2.10 -> 2.54 ms in a same-box A/B).
+    Measured at B = 32 (same box): serial kernel sum 12.02 -> 11.83 ms, images/s 2 996 -> 3 001: the up-convs used to hide on side
+    streams.  Env ROMP_FUSEUP=0: off, =all: single-image plans too.  -> number of fused outputs."""
     import os
     P.fused_ups = 0
-    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSEUP', '1') == '0':
+    mode = os.environ.get('ROMP_FUSEUP', '1')
+    if not getattr(P, 'f16x2', False) or mode == '0' or (getattr(P, 'split_k_items', 0) and mode != 'all'):
         return 0
     by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
     consumed = {}                                             # conv op index -> [fusesum op indices that took a slice of it]

@@ -323,6 +323,11 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             for k in range(op.n_terms):
                 assert written.get(op.term_buf[k], op.term_fmt[k]) == op.term_fmt[k], name
             written[op.out_buf] = op.out_fmt
+        elif op.kind == L.OP_FUSEUP:                          # a fuse sum with its 1x1 up-convs inside: every tensor H2
+            for k in range(op.n_terms):
+                assert written.get(op.term_buf[k]) == L.FMT_H2 and op.term_fmt[k] == L.FMT_H2, name
+            assert op.out_fmt == L.FMT_H2 and (op.flags & L.OPF_WAVE16) and op.weight_aux, name
+            written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM:
             written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_SEAM1X1:                         # fused Bottleneck seam: writes t (the NOP's output) and u, both H2
@@ -464,12 +469,15 @@ def test_hrnet_program_fusions_are_the_documented_ones(monkeypatch):
         for i, k in enumerate(ks):
             if k in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1):
                 assert ks[i - 1] == L.OP_NOP, (i, P.names[i])
-        return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), ks.count(L.OP_SEAM1X1), ks.count(L.OP_NOP)
-    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_BBLOCK32'):
+        return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), ks.count(L.OP_SEAM1X1), ks.count(L.OP_FUSEUP), ks.count(L.OP_FUSESUM), ks.count(L.OP_NOP)
+    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_BBLOCK32', 'ROMP_FUSEUP', 'ROMP_MERGE_S2'):
         monkeypatch.delenv(v, raising=False)
-    assert kinds() == (32, 32, 3, 67)
-    assert kinds(split_k_items=256) == (32, 0, 0, 32)
+    # round 4: 16 of the 23 fuse-layer outputs have up-terms: each runs as FUSEUP and the 18 (merged) 1x1 up-convs become NOPs
+    assert kinds() == (32, 32, 3, 16, 7, 67 + 18)
+    assert kinds(split_k_items=256) == (32, 0, 0, 0, 23, 32)
+    monkeypatch.setenv('ROMP_FUSEUP', '0')
+    assert kinds() == (32, 32, 3, 0, 23, 67)
     monkeypatch.setenv('ROMP_FUSE_BLOCKS', '0')
-    assert kinds() == (0, 0, 3, 3)
+    assert kinds() == (0, 0, 3, 0, 23, 3)
     monkeypatch.setenv('ROMP_FUSE_SEAMS', '0')
-    assert kinds() == (0, 0, 0, 0)
+    assert kinds() == (0, 0, 0, 0, 23, 0)
