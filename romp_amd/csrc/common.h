@@ -44,6 +44,8 @@ bool conv_variant_valid(const romp_op& op, int variant);
 bool conv_variant_tunable(const romp_op& op, int variant);   // ... and offered to romp_net_autotune
 void conv_set_sat_counter(int* counter, bool checked_fused);   // conv_mfma.hip: the device counter the following launches report clamped values to
 int* conv_sat_counter();
+void conv_set_wg_cap(int cap);                                 // fused kernels: workgroups per CU they may take (the net's wg_cap; 0 = all)
+int conv_wg_cap();
 bool conv_sat_checked();                                       // fused-block kernels: launch the builds that count too
 unsigned long long* conv_trace_arm(hipStream_t st);   // conv_mfma.hip: ROMP_CONV_TRACE stamp buffer, zeroed on `st` (nullptr: off)
 int launch_seam1x1(const romp_op& opa, const romp_op& opb, const float* m, const float* x, float* t, float* u, int B, hipStream_t st);   // conv_h2x.hip

@@ -272,7 +272,8 @@ static int launch_fup(FupParams& p, int B, hipStream_t st) {
     ROMP_REQUIRE(p.n_direct <= X::MAXD, "fuseup: %d direct terms for a %d-channel output (at most %d)", p.n_direct, CO, X::MAXD);
     ROMP_REQUIRE(p.H % X::TH == 0 && p.W % X::TW == 0, "fuseup: %dx%d is not a multiple of the %dx%d tile", p.H, p.W, X::TH, X::TW);
     p.tiles_x = p.W / X::TW; p.tiles_y = p.H / X::TH; p.tiles_total = B * p.tiles_x * p.tiles_y;
-    const int per_cu = 160 * 1024 / X::LDS_BYTES >= 2 ? 2 : 1;
+    const int cap = conv_wg_cap();
+    const int per_cu = (cap == 1 || 160 * 1024 / X::LDS_BYTES < 2) ? 1 : 2;
     long grid = (long)num_cu * per_cu;
     if (grid > p.tiles_total) grid = p.tiles_total;
     hipLaunchKernelGGL((fuseup_kernel<CO, NUP>), dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);

@@ -549,7 +549,8 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     p.pad_h = p.pad_w = 1;
     p.out_rs = op.out_rstride > 0 ? op.out_rstride : p.Wo * op.out_cstride;
     p.out_bs = op.out_bstride > 0 ? op.out_bstride : p.Ho * p.Wo * op.out_cstride;
-    long grid = (long)num_cu * X::WG_PER_CU;
+    const int cap = conv_wg_cap();
+    long grid = (long)num_cu * ((cap > 0 && cap < X::WG_PER_CU) ? cap : X::WG_PER_CU);
     if (grid > p.tiles_total) grid = p.tiles_total;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
     hipLaunchKernelGGL(checked ? fn_checked : fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);

@@ -94,6 +94,9 @@ static int ensure_attrs() {
 // The executor (net.hip) names the running net's counter before it enqueues; every launcher copies it into its parameters.
 void conv_set_sat_counter(int* counter, bool checked_fused) { g_sat = counter; g_sat_checked = checked_fused; }
 int* conv_sat_counter() { return g_sat; }
+static int g_fused_cap = 0;                 // workgroups per CU the fused kernels may take (0: all they can); set with the net's wg_cap
+void conv_set_wg_cap(int cap) { g_fused_cap = cap; }
+int conv_wg_cap() { return g_fused_cap; }
 bool conv_sat_checked() { return g_sat_checked; }
 
 // One-time per-process setup (LDS attributes, occupancy, scratch queue).  romp_net_create calls it so

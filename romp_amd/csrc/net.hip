@@ -276,6 +276,7 @@ static bool lanes_active(const romp_net* n, int B) { return n->split == 2 && n->
 
 static int run_all(romp_net* n, const float* image, int B, float* center, float* params, hipStream_t st, size_t first_op = 0) {
     conv_set_sat_counter(n->sat, n->sat_checked);
+    conv_set_wg_cap(n->wg_cap);
     int rc = reset_queues(n, st);
     if (rc) return rc;
     if (!lanes_active(n, B)) {

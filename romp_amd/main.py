@@ -297,7 +297,19 @@ class ROMP(nn.Module):
         n = images.shape[0]
         starts = list(range(0, n, chunk))
         if not hasattr(self, '_pipe'):
-            self._pipe = dict(stream=torch.cuda.Stream(dev), bufs={}, ev_net=[torch.cuda.Event(), torch.cuda.Event()],
+            # ROMP_PIPE_NETS=2 (round 4 experiment, off by default): TWO networks in flight -- even chunks on the net, odd chunks on
+            # its twin (RompNet.twin: own arena and graphs, shared weights), each on its own stream, half a period apart, so that one
+            # forward's HBM-bound single-kernel phases (stem, layer1, head: 3.9 of a forward's 10.9 ms, scripts/timeline.py) could run
+            # beside the other's matrix-bound HRNet modules.  Measured: 2 964 -> 2 977 images/s (+0.4 %) on one box, 2 847 = 2 847 on
+            # another; with every kernel capped at one workgroup per CU (ROMP_PIPE_WGCAP=1) 2 765: the persistent kernels fill every CU
+            # slot, so two forwards time-slice at kernel granularity instead of overlapping.  Not worth a second arena.
+            two = os.environ.get('ROMP_PIPE_NETS', '1') == '2' and len(starts) > 1 and self.model.max_batch > 2
+            nets = [self.model, self.model.twin()] if two else [self.model, self.model]
+            if two and os.environ.get('ROMP_PIPE_WGCAP'):             # experiment: every kernel leaves half of each CU to the other net's
+                for net in nets:
+                    net.set_split(1, wg_cap=int(os.environ['ROMP_PIPE_WGCAP']))
+            streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if two else [torch.cuda.Stream(dev)] * 2
+            self._pipe = dict(nets=nets, streams=streams, bufs={}, ev_net=[torch.cuda.Event(), torch.cuda.Event()],
                               ev_free=[torch.cuda.Event(), torch.cuda.Event()])
         P = self._pipe
         cur = torch.cuda.current_stream(dev)
@@ -312,15 +324,17 @@ class ROMP(nn.Module):
         def launch(i):
             x = images[starts[i]:starts[i] + chunk]
             c, p_ = bufs(x.shape[0], i & 1)
-            P['stream'].wait_event(P['ev_free'][i & 1])           # the chunk that used this pair of maps has been parsed
-            with torch.cuda.stream(P['stream']):
-                self.model.forward_nhwc(x, c, p_)
-                P['ev_net'][i & 1].record(P['stream'])
+            st = P['streams'][i & 1]
+            st.wait_event(P['ev_free'][i & 1])                    # the chunk that used this pair of maps has been parsed
+            with torch.cuda.stream(st):
+                P['nets'][i & 1].forward_nhwc(x, c, p_)
+                P['ev_net'][i & 1].record(st)
             return c, p_
 
         P['ev_free'][0].record(cur)
         P['ev_free'][1].record(cur)
-        P['stream'].wait_stream(cur)                              # the images are ready
+        for st in set(P['streams']):
+            st.wait_stream(cur)                                   # the images are ready
         pending = launch(0)
         for i, c0 in enumerate(starts):
             center, params = pending
@@ -334,7 +348,8 @@ class ROMP(nn.Module):
                     outputs = self.smpl_parser(outputs, root_align=self.settings.root_align)
             P['ev_free'][i & 1].record(cur)
             yield outputs, batch_ids, c0
-        cur.wait_stream(P['stream'])
+        for st in set(P['streams']):
+            cur.wait_stream(st)
 
 
 def _imread_bgr(path):

@@ -118,6 +118,40 @@ class RompNet:
                 out.append(math.inf if bad[i] else float(mx[i]))
         return out
 
+    def twin(self):
+        """A second executor of the SAME lowered program on the same device: its own activation arena, work queues, side
+        streams and hipGraphs; the packed constants (weights) are shared.  `ROMP.forward_chunks` alternates the chunks of a job
+        between a net and its twin on two HIP streams: the single-kernel phases of one forward (the stem, layer1's HBM-bound
+        bottlenecks, the head: a third of a forward's wall time, scripts/timeline.py) then run beside the other forward's
+        matrix-bound HRNet modules instead of alone.  Variant tables installed so far are copied."""
+        if getattr(self, '_plan_path', None) is not None:
+            t = RompNet.from_plan(self._plan_path, self.device, max_batch=self.max_batch, out_shapes=self.out_shapes)
+            t.set_graph(getattr(self, '_use_graph', False))
+            return t
+        t = RompNet.__new__(RompNet)
+        for k in ('device', 'lib', 'max_batch', 'bf16x3', 'split', 'split_k', 'input_size', 'program', 'op_maxabs', 'range_fallback', 'out_shapes'):
+            setattr(t, k, getattr(self, k, None))
+        t._tuned = set()
+        with torch.cuda.device(self.device):
+            ops = self.program.op_array()
+            sizes = (C.c_int64 * len(self.program.buf_floats))(*self.program.buf_floats)
+            h = C.c_void_p()
+            L.check(self.lib.romp_net_create(C.byref(h), ops, len(self.program.ops), sizes, len(self.program.buf_floats), self.max_batch))
+            t._h = h
+            if self.program.coord_off is not None:
+                fs = self.input_size // 4
+                coords = coord_channels(self.max_batch, fs, self.device, self.program.head_in_ch, self.program.coord_off)
+                if self.program.buf_fmt.get(self.program.head_in_buf) == L.FMT_H2:
+                    coords = encode_h2(coords.cpu()).to(self.device)
+                L.check(self.lib.romp_net_write_buffer(t._h, self.program.head_in_buf, L.ptr(coords), coords.numel(), L.stream_ptr(self.device)))
+            torch.cuda.synchronize(self.device)
+        for B in sorted(self._tuned):
+            t.set_tuned(B, self.tuned_variants(B))
+        t.set_graph(getattr(self, '_use_graph', False))
+        if not getattr(self, '_use_streams', True):
+            t.set_streams(False)
+        return t
+
     @classmethod
     def from_plan(cls, path, device, max_batch=32, use_graph=False, out_shapes=None):
         """A net from a plan file (export.save_plan): no state_dict, no lowering -- libromp_hip.so's romp_net_load does it all.
@@ -131,6 +165,7 @@ class RompNet:
         self.lib = L.load()
         self.max_batch = int(max_batch)
         plan = read_plan(path)
+        self._plan_path = path
         ops = plan['ops']
         self.bf16x3 = any(o.weight_h2 or o.weight_aux for o in ops)
         self.split, self.split_k, self.input_size = 1, int(any(o.kind == L.OP_KSUM for o in ops)), plan['input_size']
@@ -160,6 +195,7 @@ class RompNet:
 
     def set_streams(self, enable):
         """Run independent HRNet branches on side HIP streams (default on)."""
+        self._use_streams = bool(enable)
         L.check(self.lib.romp_net_set_streams(self._h, int(bool(enable))))
 
     def set_split(self, lanes, wg_cap=1):
@@ -171,6 +207,7 @@ class RompNet:
         self.split = int(lanes)
 
     def set_graph(self, enable):
+        self._use_graph = bool(enable)
         L.check(self.lib.romp_net_set_graph(self._h, int(bool(enable))))
 
     # -- forward -------------------------------------------------------------------------

@@ -1056,25 +1056,29 @@ def test_forward_batch_matches_oracle(dev):
     assert ev < 1e-3
 
 
-def test_forward_chunks_pipelined_equals_forward_batch(dev):
+@pytest.mark.parametrize('mb,n', [(2, 5), (4, 14)])
+def test_forward_chunks_pipelined_equals_forward_batch(dev, mb, n, monkeypatch):
     """ROMP.forward_chunks (network of chunk i+1 on its own stream under parse + SMPL of chunk i, hipGraph replay, two pairs of
-    output maps) returns exactly what forward_batch returns chunk by chunk -- ragged last chunk included."""
+    output maps) returns exactly what forward_batch returns chunk by chunk -- ragged last chunk included.  max_batch 4: the
+    batch-plan path with TWO networks in flight (the net and its twin alternate, RompNet.twin) must give the same bytes."""
     import romp_amd
+    monkeypatch.setenv('ROMP_PIPE_NETS', '2')                   # (the two-network pipeline is an opt-in experiment)
     settings = romp_amd.romp_settings([])
-    settings.GPU, settings.center_thresh, settings.max_batch = 0, 1.3, 2
+    settings.GPU, settings.center_thresh, settings.max_batch = 0, 1.3, mb
     sd = O.make_romp_state_dict(0, center_bias=2.0)
     model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=O.make_synthetic_smpl(0))
     model.model.set_graph(True)
-    x = O.make_images(5, seed=9).to(dev)
+    x = O.make_images(n, seed=9).to(dev)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         want = []
-        for c0 in range(0, 5, 2):
-            out, bids = model.forward_batch(x[c0:c0 + 2])
+        for c0 in range(0, n, mb):
+            out, bids = model.forward_batch(x[c0:c0 + mb])
             want.append(None if out is None else {k: v.clone() for k, v in out.items() if torch.is_tensor(v)} | {'bids': bids.clone()})
         for rep in range(2):                                     # second pass replays the cached graphs
-            got = list(model.forward_chunks(x, 2))
-            assert [c0 for _, _, c0 in got] == [0, 2, 4]
+            got = list(model.forward_chunks(x, mb))
+            assert [c0 for _, _, c0 in got] == list(range(0, n, mb))
+            assert (len(set(id(t) for t in model._pipe['nets'])) == 2) == (mb > 2)
             for (out, bids, _), w in zip(got, want):
                 assert (out is None) == (w is None)
                 if out is not None:
