@@ -759,8 +759,15 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
         P.free(r)
         x = y
     # ---- transition1 (model.py:393-398)
-    xs = [cbr('transition1.0', x, bb + 'transition1.0.0', bb + 'transition1.0.1', 3, 1, True),
-          cbr('transition1.1', x, bb + 'transition1.1.0.0', bb + 'transition1.1.0.1', 3, 2, True)]
+    # (the two transition convs read the same tensor and are independent: two streams -- scripts/timeline.py counts 3.9 ms of a
+    # forward with a single kernel in flight; every pair that can co-run takes some of it back)
+    P.fork(1)
+    P.on(0)
+    t10 = cbr('transition1.0', x, bb + 'transition1.0.0', bb + 'transition1.0.1', 3, 1, True)
+    P.on(1)
+    t11 = cbr('transition1.1', x, bb + 'transition1.1.0.0', bb + 'transition1.1.0.1', 3, 2, True)
+    P.join()
+    xs = [t10, t11]
     P.free(x)
 
     import os
@@ -922,7 +929,9 @@ def build_romp_head(P: Program, sd, head_x: Act, cin: int):
         P.free(u)
         P.free(t)
         t = v
+    P.fork(len(heads) - 1)                                       # the three output convs are independent: one stream each
     for gi, h in enumerate(heads):
+        P.on(gi)
         p = f'final_layers.{h}.2'
         w = sd[p + '.weight']
         s, b = fold_bn(sd, None, w.shape[0], sd[p + '.bias'])
@@ -932,6 +941,7 @@ def build_romp_head(P: Program, sd, head_x: Act, cin: int):
         else:   # params_maps = cat([cam_maps, params_maps], 1)  (model.py:480)
             P.conv('head.params' if h == 1 else 'head.cam', xin, [w], [s], [b], 1, 1, False,
                    out_buf_special=BUF_PARAMS, out_cstride=145, out_coff=3 if h == 1 else 0)
+    P.join()
     P.free(t)
 
 
