@@ -45,15 +45,26 @@ MODES = {
     'f16x2_4': (torch.float16, 2, [(0, 0), (0, 1), (1, 0), (1, 1)]),
     'f16x1_1': (torch.float16, 1, [(0, 0)]),
     'f16_x2w1_2': (torch.float16, 2, [(0, 0), (1, 0)]),       # activations 2 pieces, weights 1 piece
+    'f16_x1w2_2': (torch.float16, 2, [(0, 0), (0, 1)]),       # activations 1 piece, weights 2 pieces
 }
+# "<mode>%<substring>": the mode only for convs whose state_dict name contains the substring, f16x2_3 (the product path) elsewhere
 
 
-def make_conv(mode, act_scale_target=None):
-    dt, n, prods = MODES[mode]
-    stats = {'max_act': 0.0}
+def make_conv(mode, act_scale_target=None, only=None):
+    dt, n, prods0 = MODES[mode]
+    stats = {'max_act': 0.0, 'hit': 0, 'flops_hit': 0.0, 'flops': 0.0}
 
     def conv(x, sd, name, stride=1):
         w = sd[name + '.weight']
+        fl = float(w.numel()) * x.shape[2] * x.shape[3] / (stride * stride)
+        stats['flops'] += fl
+        prods = prods0
+        if only is not None:
+            if only in name and w.shape[-1] == 3:
+                stats['hit'] += 1
+                stats['flops_hit'] += fl
+            else:
+                prods = MODES['f16x2_3'][2]
         sx = sw = 1.0
         if dt == torch.float16:
             # per-tensor power-of-two scales (exact): keep the low pieces out of the fp16 subnormal range
@@ -87,16 +98,19 @@ def main():
     O.coord_maps = orig_coord
     print('f32 oracle vs f64: center %.3e params %.3e' % (float((cm32 - cm64).abs().max()), float((pm32 - pm64).abs().max())))
     for mode in sys.argv[2:] or MODES:
-        fixed = None
+        fixed = only = None
+        if '%' in mode:
+            mode, only = mode.split('%')
         if '@' in mode:
             mode, fixed = mode.split('@')
             fixed = float(fixed)
-        O._conv, stats = make_conv(mode, fixed)
+        O._conv, stats = make_conv(mode, fixed, only)
         cm, pm = O.romp_net_forward(sd, img)
         O._conv = orig_conv
         print('%-12s vs f32 oracle: center %.3e params %.3e | vs f64: center %.3e params %.3e  (max act %.1f)' % (
             mode + ('@%g' % fixed if fixed else ''), float((cm - cm32).abs().max()), float((pm - pm32).abs().max()),
-            float((cm - cm64).abs().max()), float((pm - pm64).abs().max()), stats['max_act']), flush=True)
+            float((cm - cm64).abs().max()), float((pm - pm64).abs().max()), stats['max_act']) +
+              ('  [%s: %d convs, %.0f %% of the MACs]' % (only, stats['hit'], 100.0 * stats['flops_hit'] / max(stats['flops'], 1.0)) if only else ''), flush=True)
 
 
 if __name__ == '__main__':
