@@ -430,6 +430,7 @@ def bench_bev(args, dev):
     model = bev.BEV(s, state_dict=sd, smpla_model=smpla, smil_model=smil)
     images = S.make_images(args.batch, seed=4, device=dev)
     net = model.model.net
+    net.set_streams(args.streams)
     variant_table = install_variants(args, net, args.batch, 0, 'bev-hrnet32', lambda m: print('bench.py: ' + m, file=sys.stderr, flush=True))
     pads = torch.tensor([[0., 512., 0., 512., 512., 512.]]).repeat(args.batch, 1)
     # random weights have no calibrated confidence: bisect (outside the timed region) for the threshold that keeps
@@ -460,6 +461,11 @@ def bench_bev(args, dev):
            'config': {'workload': 'BEV HRNet-32 + BEV head 512x512 batch=%d (BASELINE configs[3]); net+3D parse+'
                                   'regression+SMPL-A+post-processing' % args.batch,
                       'persons_kept_per_image': round(n / args.batch, 2), 'center_thresh': round(mid, 4), 'variant_table': variant_table}}
+    if args.dump_op_kernels:
+        json.dump({'batch': args.batch, 'names': net.variant_names(args.batch), 'op_names': list(net.program.names),
+                   'kinds': [int(o.kind) for o in net.program.ops],
+                   'bytes': [float(b) * args.batch for b in net.program.bytes], 'flops': [float(f) * args.batch for f in net.program.flops]},
+                  open(args.dump_op_kernels, 'w'))
     if not args.no_roofline:
         s1 = torch.cuda.Stream(dev)
         with torch.cuda.stream(s1):
