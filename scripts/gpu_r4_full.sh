@@ -4,8 +4,8 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -x --timeout 900 > gpurun_out/full_tests.log 2>&1
-echo "== pytest -m gpu: exit $? :: $(tail -n 1 gpurun_out/full_tests.log)"
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -x --timeout 900 --durations=12 > gpurun_out/full_tests.log 2>&1
+echo "== pytest -m gpu: exit $? :: $(tail -n 1 gpurun_out/full_tests.log)"; grep -E "^[0-9.]+s (call|setup)" gpurun_out/full_tests.log | head -12
 grep -hE "FAILED|Error" gpurun_out/full_tests.log | head -20
 timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "== smoke: exit $? :: $(tail -n 1 gpurun_out/smoke.log)"
 timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; echo "== bench: exit $?"
@@ -14,8 +14,8 @@ for W in bev resnet50 b128 smpl; do
   case $W in
     bev) A="--workload bev";; resnet50) A="--backbone resnet50";; b128) A="--batch 128";; smpl) A="--workload smpl";;
   esac
-  rm -f gpurun_out/tune_$W.json
-  T=""; [ $W != smpl ] && T="--tune-file gpurun_out/tune_$W.json"
+
+  T=""
   timeout 900 python bench.py $A $T --no-f32-companion --no-latency > gpurun_out/bench_$W.log 2>&1; echo "== bench $W: exit $?"
   grep '^{' gpurun_out/bench_$W.log | tail -1 > gpurun_out/bench_$W.json
 done
