@@ -48,6 +48,7 @@ static void collect_variants() {
     t = conv_variants_h2d(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2r(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2s(&n); kVariants.insert(kVariants.end(), t, t + n);
+    t = conv_variants_h2k(&n); kVariants.insert(kVariants.end(), t, t + n);
     kNumVariants = (int)kVariants.size();
 }
 static bool g_attr_done = false;
@@ -108,6 +109,8 @@ static bool variant_ok(const ConvVariant& v, const romp_op& op, int Ho, int Wo) 
     if ((v.math == 1 || v.math == 2) && (op.weight_aux == nullptr || (op.cin_pad & 15))) return false;
     if (v.math >= 3 && (op.weight_h2 == nullptr || op.scale_h2 == nullptr || (op.cin_pad & 15))) return false;
     if (op.in_fmt == ROMP_FMT_H2 && v.math < 3) return false;
+    if (v.math == 10 && !(op.out_fmt == ROMP_FMT_H2 && op.Cout == op.cout_pad && (op.res_buf == ROMP_BUF_NONE || op.res_fmt == ROMP_FMT_H2) &&
+                          op.out_rstride == 0 && op.out_bstride == 0)) return false;      // conv_h2k: the direct H2 epilogue is its only one
     if (v.math >= 8 && op.in_fmt != ROMP_FMT_H2) return false;                         // register-weight kernels: pixels arrive by LDS-DMA too   // the DMA pipeline copies pre-split pixels
     if ((op.out_fmt == ROMP_FMT_H2 || op.res_fmt == ROMP_FMT_H2) && !(op.Cout == op.cout_pad)) return false;   // vector epilogue only
     if (v.ks != op.ksize || v.s != op.stride) return false;
@@ -282,7 +285,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 9 ? "conv_h2s" : v.math == 8 ? "conv_h2r" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 10 ? "conv_h2k" : v.math == 9 ? "conv_h2s" : v.math == 8 ? "conv_h2r" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }

@@ -83,8 +83,6 @@ class RompNet:
         a few calibration frames -> list aligned with self.program.ops (None where an op writes no arena buffer)."""
         import math
         P32 = builder(state_dict, self.device, input_size, bf16x3='f32', **kw)
-        assert len(P32.ops) == len(self.program.ops) and all(a.kind == b.kind for a, b in zip(P32.ops, self.program.ops)), \
-            'the float32 lowering must have the same op list'
         if calib_images is None:
             g = torch.Generator(device='cpu').manual_seed(20240924)
             lin = torch.linspace(0, 255, input_size)
@@ -110,12 +108,24 @@ class RompNet:
             L.check(self.lib.romp_net_range_scan(h, L.ptr(calib_images[:B]), B, L.ptr(c), L.ptr(q), L.stream_ptr(self.device), mx, bad, None))
         finally:
             self.lib.romp_net_destroy(h)
-        out = []
+        # The two lowerings name their layers alike but need not have the same op list: a single-image float32 program splits the
+        # input channels of its deep 3x3 layers into `<name>.splitk` + `<name>.ksum`, the f16x2 program runs them as ONE conv on
+        # csrc/conv_h2k.hip.  A layer's output tensor is what its last op wrote: matched by layer name.
+        by_name = {}
         for i, op in enumerate(P32.ops):
-            if op.out_buf < 0 or op.kind in (L.OP_FORK, L.OP_JOIN):
+            if op.out_buf < 0 or op.kind in (L.OP_FORK, L.OP_JOIN) or P32.names[i].endswith('.splitk'):
+                continue
+            name = P32.names[i][:-len('.ksum')] if P32.names[i].endswith('.ksum') else P32.names[i]
+            by_name[name] = math.inf if bad[i] else float(mx[i])
+        out = []
+        for i, op in enumerate(self.program.ops):
+            name = self.program.names[i]
+            if op.out_buf < 0 or op.kind in (L.OP_FORK, L.OP_JOIN) or name.endswith('.splitk'):
                 out.append(None)
-            else:
-                out.append(math.inf if bad[i] else float(mx[i]))
+                continue
+            key = name[:-len('.ksum')] if name.endswith('.ksum') else name
+            assert key in by_name, 'calibration: layer %s of the program has no counterpart in the float32 lowering' % key
+            out.append(by_name[key])
         return out
 
     def twin(self):

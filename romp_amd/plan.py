@@ -558,6 +558,11 @@ class Program:
         ksum_kernel adds the partial sums)."""
         if self.split_k_items <= 0 or ksize not in (1, 3) or Wo % 16 or cout % 8:
             return 1
+        import os
+        if (self.f16x2 and ksize == 3 and stride == 1 and cin % 64 == 0 and cout % 32 == 0 and os.environ.get('ROMP_KSPLIT_WG', '1') != '0'):
+            # round 4: csrc/conv_h2k.hip splits the input channels across the WAVES of a workgroup and reduces in LDS -- the layer
+            # stays one conv op (no float32 partial tensors, no ksum launch); the autotuner picks it wherever the tensors are H2
+            return 1
         items = -(-Ho // 8) * (Wo // 16) * -(-cout // 32)
         g = 1
         while items * g < self.split_k_items and cin % (2 * g) == 0 and cin // (2 * g) >= 32 and (cin // (2 * g)) % 16 == 0:

@@ -28,12 +28,14 @@ def kernel_of(variant_name):
         return ('seam1x1_kernel',)
     if variant_name == 'fuseup':
         return ('fuseup_kernel',)
-    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2s|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2s|h2k|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
     fam, ks, s, mt, nt, tw, ck = m.groups()
     if fam == 'h2r':                                         # conv_h2r_kernel<P, NS, TW, KSUB>: ck = 16 * KSUB
         return 'conv_h2r_kernel<%s, %s, %s, %d>' % (mt, nt, tw, int(ck) // 16)
+    if fam == 'h2k':
+        return 'conv_h2k_kernel<%s, %s>' % (mt, tw)
     if fam in ('h2q', 'h2s'):
         return 'conv_%s_kernel<%s, %s, %s>' % (fam, mt, nt, tw)
     if fam in ('h2p', 'h2w'):
