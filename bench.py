@@ -79,7 +79,7 @@ def parse_args():
 
 
 # ------------------------------------------------------------------------------------------------ roofline
-def pmc_traffic(op_ids, op_names, pmc_dir, workload=''):
+def pmc_traffic(op_ids, op_names, pmc_dir, workload='', layer_names=None):
     """Measured HBM bytes per launch over the op index set `op_ids`, from the committed rocprofv3 --pmc passes of this same
     command (profiles/<tag><workload>_pmc_traffic_by_op.json, written by scripts/summarize_pmc.py --by-op from separate
     FETCH_SIZE / WRITE_SIZE passes: per op index the mean over the profiled forwards of 2 * FETCH_SIZE + WRITE_SIZE, the
@@ -89,9 +89,10 @@ def pmc_traffic(op_ids, op_names, pmc_dir, workload=''):
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
+    by_layer = {e['layer']: e for e in t['ops'].values() if 'layer' in e}      # (op indices move when stream markers are added; layer names do not)
     tot = 0.0
     for i in op_ids:
-        e = t['ops'].get(str(i))
+        e = by_layer.get(layer_names[i]) if (by_layer and layer_names is not None) else t['ops'].get(str(i))
         if e is None or e['kernel'] != op_names[i]:
             return None
         tot += e['bytes']
@@ -146,7 +147,7 @@ def roofline_report(net, images, pmc_workload=None):
     # DEFAULT workload (profiles/README.md) and is reported only for that workload (a kernel name alone does not identify the
     # layers behind it: the ResNet-50 / BEV / other-batch lines carry null) and only if the dominant kernel is in those passes
     # pmc_workload: '' = the default workload, '_resnet50' / '_bev' = their own passes, None = no passes for this configuration
-    t = pmc_traffic(a['ops'], op_names, os.path.join(ROOT, 'profiles'), pmc_workload) if pmc_workload is not None else None
+    t = pmc_traffic(a['ops'], op_names, os.path.join(ROOT, 'profiles'), pmc_workload, list(net.program.names)) if pmc_workload is not None else None
     if t is None:
         roof['traffic_note'] = ('null: no committed PMC passes (profiles/%s*_pmc_traffic_by_op.json) for this configuration, or they were '
                                 'taken with another kernel-variant table' % PROFILE_TAG)

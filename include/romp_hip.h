@@ -94,6 +94,12 @@ const char* romp_last_error(void);
                                    SOURCE x_s (Cout << s dense channels at 1 / 2^s resolution).  weight_aux: the f16x2 weights W_s, each
                                    repacked per 16-channel group (plan.pack_h2_wave16), concatenated; scale_h2 / shift: [s][Cout].
                                    H2 tensors throughout; Cout 32 | 64 | 128; H x W = the OUTPUT size                            */
+#define ROMP_OP_RECORD    17    /* stream `stream` (0 = main, 1..3 = side) records event number `Cin` here ..                     */
+#define ROMP_OP_WAIT      18    /* .. and stream `stream` goes on only when event `Cin` (recorded EARLIER in op order) has fired:
+                                   point-to-point edges between the streams of an open FORK .. JOIN region (plan.hr_module, round 4:
+                                   an HRNet stage is one region; a fuse output waits for exactly the tensors it sums, the next
+                                   module's branch follows its own fuse output in stream order).  Event numbers are unique per
+                                   program; with streams off both kinds do nothing (op order is a valid serial order)           */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 /* romp_op.flags */

@@ -18,10 +18,10 @@
 
 namespace romp {
 
-template <int P, int TW>
+template <int KS, int P, int TW>                               // KS = 3: 3x3, 1: 1x1 (the 1x1 up-convs of a single-image plan)
 struct KCfg {
-    static constexpr int NWV = 4;
-    using C = ConvCfg<3, 1, P, 1, TW, 16, 1>;                  // TH = P * (32 / TW) rows, NW = 32 channels
+    static constexpr int NWV = 4, TAPS = KS * KS;
+    using C = ConvCfg<KS, 1, P, 1, TW, 16, 1>;                 // TH = P * (32 / TW) rows, NW = 32 channels
     static constexpr int CG = (C::HC + 3) / 4;                 // 4-pixel column groups per haloed row
     static constexpr int RSU = CG * 16;                        // 16-byte units per haloed row
     static constexpr int NIW = (C::HR * RSU + 63) / 64;        // DMA pieces (wave-instructions of 1 KiB) of ONE wave's chunk
@@ -30,7 +30,7 @@ struct KCfg {
     static constexpr int OFF_R = 2 * STAGE_BYTES;              // reduction tiles: [block][wave][channel quad g4][lane] float4
     static constexpr int RED_BYTES = P * NWV * 4 * 64 * 16;
     static constexpr int LDS_BYTES = OFF_R + RED_BYTES + 16;
-    static_assert(NIW <= 9, "at most one DMA piece per tap");
+    static_assert(KS == 1 || KS == 3, "1x1 or 3x3");
     static_assert((C::HR - 1) * RSU * 16 + RSU * 16 < 65536, "fragment read offsets are ds_read immediates");
 };
 
@@ -43,10 +43,11 @@ struct KStage {                 // wave-uniform description of one of this wave'
     int iy0, ix0, c0;
 };
 
-template <int P, int TW>
+template <int KS, int P, int TW>
 __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
     if (p.dbg & 32) return;
-    using X = KCfg<P, TW>;
+    using X = KCfg<KS, P, TW>;
+    constexpr int TAPS = X::TAPS;
     using C = typename X::C;
     using frag = f16x8;
     typedef unsigned u32x2_k __attribute__((ext_vector_type(2)));
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
         KStage d;
         d.c0 = (s * NWV + wave) * 16;
         d.in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs + d.c0;
-        d.wg = p.wh + (size_t)it.g * (9 * cin16 * 4 * p.cout_pad) + (d.c0 >> 4) * 4 * p.cout_pad + it.n0;
+        d.wg = p.wh + (size_t)it.g * (TAPS * cin16 * 4 * p.cout_pad) + (d.c0 >> 4) * 4 * p.cout_pad + it.n0;
         d.iy0 = it.ty * C::TH - p.pad_h;
         d.ix0 = it.tx * TW - p.pad_w;
         return d;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
         const unsigned long long a = ok ? a_in : (unsigned long long)p.zero;
         __builtin_amdgcn_global_load_lds((glb_void_k*)a, (lds_void_k*)(sBuf + buf * X::STAGE_BYTES + wave * X::SUB_BYTES + k * 1024), 16, 0, 0);
     };
-    frag wreg[9][2];
+    frag wreg[TAPS][2];
     const unsigned w_lane = (unsigned)(lh * p.cout_pad + li);
     const unsigned w_tap = (unsigned)(cin16 * 4 * p.cout_pad), w_pc = (unsigned)(2 * p.cout_pad);
     auto load_w = [&](const uint4*& wp, int tap) {
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
         wreg[tap][1] = __builtin_bit_cast(frag, wp[w_pc]);
         wp += w_tap;
     };
-    int xa[3][2];                                              // fragment addresses of block 0: pixel (row, col + dx), unit 2 lh + piece
+    int xa[KS][2];                                             // fragment addresses of block 0: pixel (row, col + dx), unit 2 lh + piece
     {
         const int prow = li / TW, pcol = li % TW;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+        for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
                 const int col = pcol + dx, w = lh * 2 + pc;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
         for (int k = 0; k < X::NIW; ++k) issue_piece(k, d0, 0);
         const uint4* wp0 = d0.wg + w_lane;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) load_w(wp0, tap);
+        for (int tap = 0; tap < TAPS; ++tap) load_w(wp0, tap);
     }
     f32x16 acc[P];
 #pragma unroll
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
             const char* sA = sBuf + buf * X::STAGE_BYTES + wave * X::SUB_BYTES;
             const uint4* wp = nd.wg + w_lane;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap % 3;
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int dy = tap / KS, dx = tap % KS;
                 frag x[P][2];
 #pragma unroll
                 for (int j = 0; j < P; ++j)
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
                 load_w(wp, tap);                               // the tap's registers take the next chunk's weights
                 if (tap < X::NIW) issue_piece(tap, nd, buf ^ 1);
             }
+#pragma unroll
+            for (int k = TAPS; k < X::NIW; ++k) issue_piece(k, nd, buf ^ 1);      // (1x1: more pieces than taps)
         }
         buf ^= 1;
         if (!last) { ++s; continue; }
@@ -257,10 +260,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
 }
 
 // math 10: the input channels split across the workgroup's waves; `ck` = 64 (a super-stage)
-#define ROMP_CONV_VARIANT_H2K(P, TW)                                                                   \
-    { 3, 1, P, 1, TW, 64, conv_h2k_kernel<P, TW>, KCfg<P, TW>::LDS_BYTES, KCfg<P, TW>::C::TH, 0, 0, 10, 256 }
+#define ROMP_CONV_VARIANT_H2K(KS, P, TW)                                                               \
+    { KS, 1, P, 1, TW, 64, conv_h2k_kernel<KS, P, TW>, KCfg<KS, P, TW>::LDS_BYTES, KCfg<KS, P, TW>::C::TH, 0, 0, 10, 256 }
 
-static ConvVariant kVariantsH2k[] = { ROMP_CONV_VARIANT_H2K(1, 16), ROMP_CONV_VARIANT_H2K(2, 16) };
+static ConvVariant kVariantsH2k[] = { ROMP_CONV_VARIANT_H2K(3, 1, 16), ROMP_CONV_VARIANT_H2K(3, 2, 16), ROMP_CONV_VARIANT_H2K(1, 1, 16) };
 ConvVariant* conv_variants_h2k(int* n) { *n = (int)(sizeof(kVariantsH2k) / sizeof(kVariantsH2k[0])); return kVariantsH2k; }
 
 }  // namespace romp

@@ -15,6 +15,9 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <signal.h>
+#include <execinfo.h>
+#include <unistd.h>
 
 namespace romp {
 
@@ -58,10 +61,12 @@ struct romp_net {
     int wg_cap = 0;                      // workgroups per CU a conv may take (0: all it can)
     int64_t image_floats = 0, center_floats = 0, params_floats = 0;   // per image, for the lane offsets
     hipStream_t lane_main = nullptr;     // lane 1's main stream
+    hipStream_t scratch = nullptr;       // build_graph: the stream every op is captured on, alone
     hipStream_t side[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     hipEvent_t ev_fork[2] = {nullptr, nullptr};
     hipEvent_t ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     hipEvent_t ev_begin = nullptr, ev_offset = nullptr, ev_done = nullptr;
+    std::vector<hipEvent_t> ev_edge[2];  // ROMP_OP_RECORD / ROMP_OP_WAIT events, per lane
     std::map<int, std::vector<int>> tuned;   // batch -> variant per op (-1: heuristic)
     std::map<GraphKey, hipGraphExec_t> graphs;
     // a net loaded from a plan file (romp_net_load) owns its constants; one built by romp_net_create borrows the host's
@@ -213,6 +218,8 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
         case ROMP_OP_NOP:
         case ROMP_OP_FORK:
         case ROMP_OP_JOIN:
+        case ROMP_OP_RECORD:
+        case ROMP_OP_WAIT:
             return ROMP_OK;              // stream markers: handled by run_all; NOP: fused into the next op
         default:
             set_error("unknown op kind %d", op.kind);
@@ -264,11 +271,116 @@ static int run_lane(romp_net* n, const float* image, int B, float* center, float
             continue;
         }
         hipStream_t s = (ms && op.stream >= 1 && op.stream <= 3) ? n->side[lane][op.stream - 1] : st;
+        if (op.kind == ROMP_OP_RECORD || op.kind == ROMP_OP_WAIT) {
+            if (!ms) continue;
+            ROMP_REQUIRE(op.Cin >= 0 && op.Cin < (int)n->ev_edge[lane].size(), "record / wait: event %d of %d", op.Cin, (int)n->ev_edge[lane].size());
+            if (op.kind == ROMP_OP_RECORD) ROMP_HIP_CHECK(hipEventRecord(n->ev_edge[lane][op.Cin], s));
+            else ROMP_HIP_CHECK(hipStreamWaitEvent(s, n->ev_edge[lane][op.Cin], 0));
+            continue;
+        }
         const int rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, s, lane, b0);
         if (rc) return rc;
         if (ev_after_first_convs && op.kind == ROMP_OP_CONV && ++convs_seen == 2)      // lane 1 starts ~two layers behind lane 0
             ROMP_HIP_CHECK(hipEventRecord(ev_after_first_convs, st));
     }
+    return ROMP_OK;
+}
+
+// The forward's hipGraph, built EXPLICITLY (round 4).  Rounds 1-3 captured run_lane with its side streams; the stage region's
+// point-to-point edges cannot be captured on this runtime: hipStreamWaitEvent during a capture appends every non-origin waiting stream
+// to the recording stream's list of parallel capture streams, two side streams that wait for each other form a cycle, and
+// hipStreamEndCapture walks those lists recursively -- off the end of the stack (ROCm 7.0 / 7.2; backtrace in profiles/r04_notes.md).
+// So: every op is captured ALONE on a scratch stream (a one-stream capture: a chain of kernel / memset nodes), its nodes are re-added
+// to the forward's graph, and the dependencies come from the program: stream order, FORK / JOIN, RECORD / WAIT.  `whole`: a whole
+// forward (queue reset in front, as run_all) -- otherwise one batch lane (as run_lane; the caller resets the queues).
+static int build_graph(romp_net* n, const float* image, int B, float* center, float* params, int lane, int b0, size_t first_op, bool whole,
+                       hipGraph_t* out) {
+    typedef std::vector<hipGraphNode_t> Nodes;
+    hipGraph_t G = nullptr;
+    ROMP_HIP_CHECK(hipGraphCreate(&G, 0));
+    Nodes frontier[4];                                         // per stream: the nodes its next op depends on
+    std::map<int, Nodes> events;
+    auto merge = [](Nodes& into, const Nodes& from) {
+        for (hipGraphNode_t x : from)
+            if (std::find(into.begin(), into.end(), x) == into.end()) into.push_back(x);
+    };
+    auto fail = [&](int rc) { hipGraphDestroy(G); return rc; };
+    auto add_op = [&](int s, auto&& body) -> int {             // capture `body` on the scratch stream, move its nodes behind frontier[s]
+        hipGraph_t g1 = nullptr;
+        ROMP_HIP_CHECK(hipStreamBeginCapture(n->scratch, hipStreamCaptureModeThreadLocal));
+        const int rc = body(n->scratch);
+        const hipError_t e = hipStreamEndCapture(n->scratch, &g1);
+        if (rc) { if (g1) hipGraphDestroy(g1); return rc; }
+        ROMP_HIP_CHECK(e);
+        size_t cnt = 0;
+        ROMP_HIP_CHECK(hipGraphGetNodes(g1, nullptr, &cnt));
+        if (cnt) {
+            size_t n_root = 0;
+            ROMP_HIP_CHECK(hipGraphGetRootNodes(g1, nullptr, &n_root));
+            ROMP_REQUIRE(n_root == 1, "build_graph: an op captured as %zu root nodes (a chain is expected)", n_root);
+            hipGraphNode_t cur = nullptr;
+            ROMP_HIP_CHECK(hipGraphGetRootNodes(g1, &cur, &n_root));
+            for (size_t k = 0; k < cnt; ++k) {
+                hipGraphNodeType type;
+                ROMP_HIP_CHECK(hipGraphNodeGetType(cur, &type));
+                hipGraphNode_t nn = nullptr;
+                if (type == hipGraphNodeTypeKernel) {
+                    hipKernelNodeParams kp;
+                    ROMP_HIP_CHECK(hipGraphKernelNodeGetParams(cur, &kp));
+                    ROMP_HIP_CHECK(hipGraphAddKernelNode(&nn, G, frontier[s].data(), frontier[s].size(), &kp));
+                } else if (type == hipGraphNodeTypeMemset) {
+                    hipMemsetParams mp;
+                    ROMP_HIP_CHECK(hipGraphMemsetNodeGetParams(cur, &mp));
+                    ROMP_HIP_CHECK(hipGraphAddMemsetNode(&nn, G, frontier[s].data(), frontier[s].size(), &mp));
+                } else {
+                    set_error("build_graph: an op captured a node of type %d", (int)type);
+                    hipGraphDestroy(g1);
+                    return ROMP_EHIP;
+                }
+                frontier[s].assign(1, nn);
+                if (k + 1 < cnt) {
+                    size_t n_next = 0;
+                    ROMP_HIP_CHECK(hipGraphNodeGetDependentNodes(cur, nullptr, &n_next));
+                    ROMP_REQUIRE(n_next == 1, "build_graph: a captured node has %zu dependents (a chain is expected)", n_next);
+                    ROMP_HIP_CHECK(hipGraphNodeGetDependentNodes(cur, &cur, &n_next));
+                }
+            }
+        }
+        ROMP_HIP_CHECK(hipGraphDestroy(g1));
+        return ROMP_OK;
+    };
+    conv_set_sat_counter(n->sat, n->sat_checked);
+    const int cap = n->wg_cap;
+    if (whole && n->split == 2) n->wg_cap = 0;                 // an unsplit forward takes the whole chip (run_all)
+    conv_set_wg_cap(n->wg_cap);
+    int rc = whole ? add_op(0, [&](hipStream_t s) { return reset_queues(n, s); }) : ROMP_OK;
+    const std::vector<int>* tv = tuned_for(n, B);
+    const bool ms = n->use_streams && n->mode == 0;
+    for (size_t i = first_op; i < n->ops.size() && !rc; ++i) {
+        const romp_op& op = n->ops[i];
+        const int s = (ms && op.stream >= 1 && op.stream <= 3) ? op.stream : 0;
+        switch (op.kind) {
+            case ROMP_OP_FORK:
+                for (int k = 1; ms && k <= op.Cin && k <= 3; ++k) merge(frontier[k], frontier[0]);
+                break;
+            case ROMP_OP_JOIN:
+                for (int k = 1; ms && k <= op.Cin && k <= 3; ++k) merge(frontier[0], frontier[k]);
+                break;
+            case ROMP_OP_RECORD:
+                if (ms) events[op.Cin] = frontier[s];
+                break;
+            case ROMP_OP_WAIT:
+                if (ms) merge(frontier[s], events[op.Cin]);
+                break;
+            case ROMP_OP_NOP:
+                break;
+            default:
+                rc = add_op(s, [&](hipStream_t st) { return run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, st, lane, b0); });
+        }
+    }
+    n->wg_cap = cap;
+    if (rc) return fail(rc);
+    *out = G;
     return ROMP_OK;
 }
 
@@ -306,9 +418,32 @@ extern "C" {
 int romp_abi_version(void) { return ROMP_ABI_VERSION; }
 const char* romp_last_error(void) { return romp::g_err; }
 
+// Debugging aid (env ROMP_SEGV_BACKTRACE=1): native frames of a SIGSEGV on an alternate stack -- a crash inside the HIP runtime (graph
+// instantiation recursing off the stack, say) otherwise shows Python frames only.
+static void segv_backtrace(int sig, siginfo_t* si, void*) {
+    void* frames[64];
+    char line[128];
+    int n = snprintf(line, sizeof line, "== signal %d at address %p; innermost frames:\n", sig, si ? si->si_addr : nullptr);
+    if (write(2, line, n) < 0) _exit(139);
+    backtrace_symbols_fd(frames, backtrace(frames, 64), 2);
+    _exit(139);
+}
+
 int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const int64_t* buf_floats, int n_bufs,
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
+    {
+        static bool armed = false;
+        if (!armed && getenv("ROMP_SEGV_BACKTRACE")) {
+            armed = true;
+            static char alt[1 << 16];
+            stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof alt; ss.ss_flags = 0;
+            sigaltstack(&ss, nullptr);
+            struct sigaction sa; memset(&sa, 0, sizeof sa);
+            sa.sa_sigaction = segv_backtrace; sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+            sigaction(SIGSEGV, &sa, nullptr);
+        }
+    }
     {   // One device per process (the design: one process per GPU, torch.distributed over RCCL): the launchers cache their one-time
         // set-up -- raised dynamic-LDS limits, CU count, zero pages, occupancy -- per PROCESS.  A second net on another device would
         // silently run with the first device's, so it is refused here.
@@ -377,6 +512,7 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
     }
     { const char* e = getenv("ROMP_CHECK_FINITE"); n->sat_checked = e && e[0] && strcmp(e, "0") != 0; }
     bool ok = hipStreamCreateWithFlags(&n->lane_main, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&n->scratch, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&n->ev_begin, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&n->ev_offset, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&n->ev_done, hipEventDisableTiming) == hipSuccess;
@@ -385,6 +521,22 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
         for (int k = 0; k < 3 && ok; ++k)
             ok = hipStreamCreateWithFlags(&n->side[l][k], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&n->ev_join[l][k], hipEventDisableTiming) == hipSuccess;
+    }
+    int n_edge = 0;
+    {
+        std::vector<char> recorded;
+        for (const romp_op& op : n->ops) {
+            if (op.kind != ROMP_OP_RECORD && op.kind != ROMP_OP_WAIT) continue;
+            bool good = op.Cin >= 0 && op.Cin < 4096 && op.stream >= 0 && op.stream <= 3;
+            if (good && op.kind == ROMP_OP_RECORD) { if ((int)recorded.size() <= op.Cin) recorded.resize(op.Cin + 1, 0); recorded[op.Cin] = 1; }
+            if (good && op.kind == ROMP_OP_WAIT) good = op.Cin < (int)recorded.size() && recorded[op.Cin];       // op order is a valid serial order
+            if (!good) { set_error("record / wait op: event %d on stream %d (a wait needs an earlier record)", op.Cin, op.stream); romp_net_destroy(n); return ROMP_EINVAL; }
+            n_edge = std::max(n_edge, op.Cin + 1);
+        }
+    }
+    for (int l = 0; l < 2 && ok && n_edge > 0 && n_edge <= 4096; ++l) {
+        n->ev_edge[l].assign(n_edge, nullptr);
+        for (int k = 0; k < n_edge && ok; ++k) ok = hipEventCreateWithFlags(&n->ev_edge[l][k], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         set_error("side stream / event creation failed");
@@ -442,17 +594,15 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
         ROMP_HIP_CHECK(hipStreamSynchronize(n->lane_main));
         drop_graphs(n);
     }
-    auto capture = [&](hipStream_t origin, const GraphKey& key, auto&& body) -> int {
+    auto build = [&](const GraphKey& key, const float* im, int Bl, float* ce, float* pa, int lane, int b0, size_t first_op, bool whole) -> int {
         if (n->graphs.count(key)) return ROMP_OK;
         hipGraph_t g = nullptr;
-        ROMP_HIP_CHECK(hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal));
-        const int rc = body();
-        const hipError_t e = hipStreamEndCapture(origin, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        ROMP_HIP_CHECK(e);
+        const int rc = build_graph(n, im, Bl, ce, pa, lane, b0, first_op, whole, &g);
+        if (rc) return rc;
         hipGraphExec_t ge = nullptr;
-        ROMP_HIP_CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        const hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
+        ROMP_HIP_CHECK(e);
         n->graphs.emplace(key, ge);
         return ROMP_OK;
     };
@@ -462,21 +612,20 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
             const int rc0 = run_op(n, 0, -1, image, B, center, params, st);
             if (rc0) return rc0;
         }
-        const int rc = capture(st, key, [&] { return run_all(n, image, B, center, params, st, stem_out ? 1 : 0); });
+        const int rc = build(key, image, B, center, params, 0, 0, stem_out ? 1 : 0, true);
         if (rc) return rc;
         ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[key], st));
         return ROMP_OK;
     }
-    // Batch lanes: one graph per lane, replayed on the lane's own stream.  (Capturing both lanes with
-    // their branch side streams into ONE graph overflows the stack inside hipGraph on ROCm 7.2.)
+    // Batch lanes: one graph per lane, replayed on the lane's own stream.
     const int B0 = B / 2;
     const float* image1 = image + (size_t)B0 * n->image_floats;
     float* center1 = center + (size_t)B0 * n->center_floats;
     float* params1 = params + (size_t)B0 * n->params_floats;
     const GraphKey k0{B, image, center, params, 0}, k1{B, image, center, params, 1};
-    int rc = capture(st, k0, [&] { return run_lane(n, image, B0, center, params, st, 0, 0, nullptr); });
+    int rc = build(k0, image, B0, center, params, 0, 0, 0, false);
     if (rc) return rc;
-    rc = capture(n->lane_main, k1, [&] { return run_lane(n, image1, B0, center1, params1, n->lane_main, 1, B0, nullptr); });
+    rc = build(k1, image1, B0, center1, params1, 1, B0, 0, false);
     if (rc) return rc;
     rc = reset_queues(n, st);
     if (rc) return rc;
@@ -690,7 +839,8 @@ int romp_net_range_scan(romp_net* n, const float* image, int B, float* center, f
         rc = run_op(n, i, tv ? (*tv)[i] : -1, image, B, center, params, st);
         const romp_op& op = n->ops[i];
         if (rc == ROMP_OK && hipMemcpyAsync(d + 2 * nops + i, n->sat, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) { set_error("hipMemcpyAsync failed"); rc = ROMP_EHIP; }
-        if (rc || op.out_buf < 0 || op.out_buf >= (int)n->bufs.size() || op.kind == ROMP_OP_FORK || op.kind == ROMP_OP_JOIN || op.kind == ROMP_OP_NOP) continue;
+        if (rc || op.out_buf < 0 || op.out_buf >= (int)n->bufs.size() || op.kind == ROMP_OP_FORK || op.kind == ROMP_OP_JOIN || op.kind == ROMP_OP_NOP ||
+            op.kind == ROMP_OP_RECORD || op.kind == ROMP_OP_WAIT) continue;
         ScanRegion r;
         r.x = n->bufs[op.out_buf]; r.B = B; r.bstride = n->buf_floats[op.out_buf];
         r.h2 = op.out_fmt == ROMP_FMT_H2; r.inv_scale = ldexpf(1.f, -op.act_shift);
@@ -773,8 +923,10 @@ void romp_net_destroy(romp_net* n) {
             if (n->ev_join[l][k]) hipEventDestroy(n->ev_join[l][k]);
         }
         if (n->ev_fork[l]) hipEventDestroy(n->ev_fork[l]);
+        for (hipEvent_t e : n->ev_edge[l]) if (e) hipEventDestroy(e);
     }
     if (n->lane_main) hipStreamDestroy(n->lane_main);
+    if (n->scratch) hipStreamDestroy(n->scratch);
     if (n->ev_begin) hipEventDestroy(n->ev_begin);
     if (n->ev_offset) hipEventDestroy(n->ev_offset);
     if (n->ev_done) hipEventDestroy(n->ev_done);
@@ -808,6 +960,8 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_SEAM1X1) { snprintf(out, n, "seam1x1"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_RECORD) { snprintf(out, n, "record"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_WAIT) { snprintf(out, n, "wait"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BEV_PACK) { snprintf(out, n, "bev_pack"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BEV_MAPS) { snprintf(out, n, "bev_maps"); return ROMP_OK; }
     if (op->kind == ROMP_OP_CONV3D) { snprintf(out, n, "conv3d"); return ROMP_OK; }

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OPF_WAVE16, OPF_STEM_VALU, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -234,7 +234,7 @@ def assign_formats(P):
             g = gen_for_write(op.out_buf)
             g['uses'].append((i, 'out'))
             g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
-        elif op.kind in (OP_FORK, OP_JOIN):
+        elif op.kind in (OP_FORK, OP_JOIN, OP_RECORD, OP_WAIT):
             continue
         else:                                                # any other op: its tensors stay float32
             for b in (op.in_buf, op.res_buf):
@@ -395,7 +395,7 @@ def fuse_up_sums(P):
                    if any(P.ops[i].kind in (OP_FUSESUM,) and P.ops[i].term_buf[k] == U.out_buf for k in range(P.ops[i].n_terms))
                    or (P.ops[i].kind in (OP_CONV, OP_KSUM) and (P.ops[i].in_buf == U.out_buf or P.ops[i].res_buf == U.out_buf))]
         # (readers of a LATER live range of the same arena buffer come after its next writer: stop there)
-        nxt = [i for i in range(j + 1, len(P.ops)) if P.ops[i].out_buf == U.out_buf and P.ops[i].kind not in (OP_NOP, OP_FORK, OP_JOIN)]
+        nxt = [i for i in range(j + 1, len(P.ops)) if P.ops[i].out_buf == U.out_buf and P.ops[i].kind not in (OP_NOP, OP_FORK, OP_JOIN, OP_RECORD, OP_WAIT)]
         if nxt:
             readers = [i for i in readers if i <= nxt[0]]
         if not readers:
@@ -404,6 +404,64 @@ def fuse_up_sums(P):
             P.flops[j] = 0.0
             P.bytes[j] = 0.0
     return P.fused_ups
+
+
+def stream_races(P):
+    """Happens-before check of a lowered program: stream order + FORK / JOIN + RECORD / WAIT must order every pair of conflicting
+    accesses to an arena buffer (write -> read, read -> write, write -> write; whole buffers, channel slices ignored: conservative
+    for merged convs, whose slices share their writer anyway).  -> list of (kind, buffer, earlier op, later op).  Program.op_array()
+    refuses a program with races; tests/test_cpu_host.py runs it on every plan kind."""
+    NS = 4
+    ops = P.ops
+    vc = [[-1] * NS for _ in range(NS)]                      # vc[s][t]: the latest op of stream t that happens-before stream s's next op
+    ev, at = {}, [None] * len(ops)
+    in_par = False
+    for i, op in enumerate(ops):
+        if op.kind == OP_FORK:
+            in_par = True
+            for k in range(1, op.Cin + 1):
+                vc[k] = [max(a, b) for a, b in zip(vc[k], vc[0])]
+        elif op.kind == OP_JOIN:
+            for k in range(1, op.Cin + 1):
+                vc[0] = [max(a, b) for a, b in zip(vc[0], vc[k])]
+            in_par = False
+        elif op.kind == OP_RECORD:
+            ev[op.Cin] = list(vc[op.stream])
+        elif op.kind == OP_WAIT:
+            vc[op.stream] = [max(a, b) for a, b in zip(vc[op.stream], ev[op.Cin])]
+        elif op.kind != OP_NOP:
+            s = op.stream if in_par else 0
+            vc[s][s] = i
+            at[i] = (s, list(vc[s]))
+
+    def touched(i):
+        op, r, w = ops[i], [], []
+        srcs = [op] + ([ops[i - 1]] if op.kind in (OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1) else [])    # a fused pair: the NOP before it holds the first conv
+        for o in srcs:
+            r += [b for b in (o.in_buf, o.res_buf) if b >= 0]
+            if o.kind in (OP_FUSESUM, OP_FUSEUP):
+                r += [o.term_buf[k] for k in range(o.n_terms) if o.term_buf[k] >= 0]
+            w += [b for b in [o.out_buf] + ([o.term_buf[0]] if o.kind == OP_BEV_MAPS else []) if b >= 0]
+        return r, w
+
+    ordered = lambda i, j: at[j][1][at[i][0]] >= i           # op i happens-before op j (i earlier in op order)
+    last_w, readers, races = {}, {}, []
+    for j in range(len(ops)):
+        if at[j] is None:
+            continue
+        r, w = touched(j)
+        for b in r:
+            i = last_w.get(b)
+            if i is not None and not ordered(i, j):
+                races.append(('RAW', b, P.names[i], P.names[j]))
+            readers.setdefault(b, []).append(j)
+        for b in w:
+            i = last_w.get(b)
+            if i is not None and i != j and not ordered(i, j):
+                races.append(('WAW', b, P.names[i], P.names[j]))
+            races += [('WAR', b, P.names[i], P.names[j]) for i in readers.get(b, []) if i != j and not ordered(i, j)]
+            last_w[b], readers[b] = j, []
+    return races
 
 
 def fuse_basic_blocks(P):
@@ -477,6 +535,9 @@ class Program:
         self.buf_floats: List[int] = []
         self._free: Dict[int, List[int]] = {}
         self._pfree: Dict[int, Dict[int, List[int]]] = {}     # per-stream free lists inside a fork/join region
+        self._later: List[List] = [[], []]                     # free_later(): [this epoch, the one before] of (buffer, stream)
+        self.n_events = 0
+        self._event_stream: Dict[int, int] = {}
         self.cur_stream = 0
         self.in_parallel = False
         self.parallel = True                                   # emit FORK/JOIN (False: one stream)
@@ -515,12 +576,43 @@ class Program:
             assert act.buf not in lst, 'double free of buffer %d' % act.buf
             lst.append(act.buf)
 
+    def free_later(self, act: Act, stream=None):
+        """Inside an OPEN region (hr_module's dataflow form): a buffer that OTHER streams read goes back to `stream`'s pool (default:
+        the current one) only at the end of the NEXT epoch (epoch() = a module boundary).  By then every stream has passed a fuse
+        output of the next module, which waited for every other stream's work of that module, which follows -- in stream order --
+        that stream's reads of this module: the next writer is ordered after every reader without an edge of its own."""
+        if act.buf >= 0 and act.buf not in self.persistent:
+            if not self.in_parallel:
+                return self.free(act)
+            self._later[0].append((act.buf, self.cur_stream if stream is None else stream))
+
+    def epoch(self):
+        for buf, s in self._later[1]:
+            lst = self._pfree.setdefault(s, {}).setdefault(self.buf_floats[buf], [])
+            assert buf not in lst, 'double free of buffer %d' % buf
+            lst.append(buf)
+        self._later = [[], self._later[0]]
+
+    def record(self):
+        """ROMP_OP_RECORD on the current stream -> event number for wait() (None outside a region: one stream, op order rules)."""
+        if not self.in_parallel:
+            return None
+        self._marker(OP_RECORD, self.n_events)
+        self._event_stream[self.n_events] = self.cur_stream
+        self.n_events += 1
+        return self.n_events - 1
+
+    def wait(self, event):
+        if self.in_parallel and event is not None and self._event_stream[event] != self.cur_stream:
+            self._marker(OP_WAIT, event)
+
     def _marker(self, kind, n):
         op = RompOp()
         op.kind, op.Cin = kind, n
+        op.stream = self.cur_stream if kind in (OP_RECORD, OP_WAIT) else 0
         op.in_buf = op.out_buf = op.res_buf = BUF_NONE
         self.ops.append(op)
-        self.names.append('fork' if kind == OP_FORK else 'join')
+        self.names.append({OP_FORK: 'fork', OP_JOIN: 'join', OP_RECORD: 'record', OP_WAIT: 'wait'}[kind])
         self.flops.append(0.0)
         self.bytes.append(0.0)
 
@@ -537,6 +629,8 @@ class Program:
     def join(self):
         if self.in_parallel:
             self._marker(OP_JOIN, self._n_side)
+            self.epoch()
+            self.epoch()                                       # (a join is a full barrier: everything deferred is free now)
             for pool in self._pfree.values():
                 for size, lst in pool.items():
                     self._free.setdefault(size, []).extend(lst)
@@ -559,7 +653,7 @@ class Program:
         if self.split_k_items <= 0 or ksize not in (1, 3) or Wo % 16 or cout % 8:
             return 1
         import os
-        if (self.f16x2 and ksize == 3 and stride == 1 and cin % 64 == 0 and cout % 32 == 0 and os.environ.get('ROMP_KSPLIT_WG', '1') != '0'):
+        if (self.f16x2 and stride == 1 and cin % 64 == 0 and cout % 32 == 0 and os.environ.get('ROMP_KSPLIT_WG', '1') != '0'):
             # round 4: csrc/conv_h2k.hip splits the input channels across the WAVES of a workgroup and reduces in LDS -- the layer
             # stays one conv op (no float32 partial tensors, no ksum launch); the autotuner picks it wherever the tensors are H2
             return 1
@@ -721,6 +815,8 @@ class Program:
             fuse_basic_blocks(self)
             fuse_bottleneck_seams(self)
             fuse_up_sums(self)
+            races = stream_races(self)
+            assert not races, 'the program races across its streams: %s' % (races[:4],)
             self._lowered = True
         arr = (RompOp * len(self.ops))()
         for i, o in enumerate(self.ops):
@@ -766,17 +862,25 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
     # ---- transition1 (model.py:393-398)
     # (the two transition convs read the same tensor and are independent: two streams -- scripts/timeline.py counts 3.9 ms of a
     # forward with a single kernel in flight; every pair that can co-run takes some of it back)
-    P.fork(1)
+    import os
+    merge_s2 = os.environ.get('ROMP_MERGE_S2', '1') != '0'       # A/B switch: 0 = one launch per stride-2 conv as in rounds 1-3
+    # Round 4: the stages form ONE open fork .. join region with point-to-point edges (ROMP_OP_RECORD / ROMP_OP_WAIT) instead of two
+    # full fork/join barriers per module: branch j lives on stream j from transition1 to the last module; a fuse output waits for
+    # exactly the tensors it sums; the next module's branch follows its own fuse output in stream order.  A cross-stream hand-over
+    # costs 5-10 us on this runtime (profiles/r04_b1_timeline.txt) and a barrier idles every stream until the slowest branch is done.
+    # ROMP_DATAFLOW=0: the barrier form of rounds 1-3 (A/B runs).
+    dataflow = P.parallel and os.environ.get('ROMP_DATAFLOW', '1') != '0'
+    P.fork(3 if dataflow else 1)
     P.on(0)
     t10 = cbr('transition1.0', x, bb + 'transition1.0.0', bb + 'transition1.0.1', 3, 1, True)
     P.on(1)
     t11 = cbr('transition1.1', x, bb + 'transition1.1.0.0', bb + 'transition1.1.0.1', 3, 2, True)
-    P.join()
     xs = [t10, t11]
-    P.free(x)
-
-    import os
-    merge_s2 = os.environ.get('ROMP_MERGE_S2', '1') != '0'       # A/B switch: 0 = one launch per stride-2 conv as in rounds 1-3
+    if dataflow:
+        P.free_later(x, 0)                                       # (stream 1 reads it too)
+    else:
+        P.join()
+        P.free(x)
 
     def hr_module(prefix, xs, n_out, final_out: Optional[Act] = None):
         """HighResolutionModule.forward (model.py:226-244).  The branches are independent until the
@@ -794,7 +898,9 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
         xs = list(xs)
         ch = [x.C for x in xs]
         first, ups, temps = {}, {}, []                            # (i, j) -> Act
-        P.fork(nb - 1)
+        ev_s2, ev_up, own = {}, {}, {}                            # dataflow: events after branch j's stride-2 / up convs; own[i]: stream i's private temporaries
+        if not dataflow:
+            P.fork(nb - 1)
         for br in range(nb):
             P.on(br)
             for k in range(4):                                   # branch: 4 BasicBlocks
@@ -824,6 +930,8 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
                     q = f'{prefix}fuse_layers.{i}.{br}.'
                     first[(i, br)] = cbr(f'{q}0', xs[br], f'{q}0.0', f'{q}0.1', 3, 2, i - br != 1)
                     temps.append(first[(i, br)])
+            if dataflow and targets:
+                ev_s2[br] = P.record()
             ups_to = list(range(min(br, n_out)))                 # 1x1 conv + BN towards every output i < br; the upsample is folded into fusesum
             if len(ups_to) > 1 and merge_s2:                     # the same merge for the up-convs: one launch, xs[br] read once
                 ws, ss, bs = [], [], []
@@ -843,11 +951,22 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
                     q = f'{prefix}fuse_layers.{i}.{br}.'
                     ups[(i, br)] = cbr(q + 'up', xs[br], q + '0', q + '1', 1, 1, False)
                     temps.append(ups[(i, br)])
-        P.join()
+            if dataflow and ups_to:
+                ev_up[br] = P.record()
+            if dataflow:
+                for t in temps:                                  # written here, read on other streams: back to THIS stream's pool an epoch late
+                    P.free_later(t, br)
+                temps = []
         outs = []
-        P.fork(n_out - 1)
+        if not dataflow:
+            P.join()
+            P.fork(n_out - 1)
         for i in range(n_out):
             P.on(i)
+            if dataflow:
+                for j in range(nb):
+                    if j != i:
+                        P.wait(ev_s2[j] if j < i else ev_up[j])
             terms, shifts = [], []
             for j in range(nb):
                 q = f'{prefix}fuse_layers.{i}.{j}.'
@@ -866,6 +985,16 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
                         temps.append(t)
                     terms.append(t); shifts.append(0)
             outs.append(P.fusesum(f'{prefix}fuse.{i}', terms, shifts, True, out=final_out if n_out == 1 else None))
+            if dataflow:                                         # this stream wrote and read them: its own pool, at once
+                for t in temps:
+                    P.free(t)
+                temps = []
+        if dataflow:
+            for j in range(nb):                                  # branch 0's output is read on its own stream only (convs above, fuse.0);
+                P.on(j)                                          # the others also by the FUSEUP kernels of the outputs above them
+                (P.free if j == 0 else P.free_later)(xs[j])      # (plan.fuse_up_sums moves their 1x1 up-convs into the sums)
+            P.epoch()
+            return outs
         P.join()
         for t in temps:
             P.free(t)
@@ -873,14 +1002,25 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
             P.free(xj)
         return outs
 
+    def transition(name, src, conv, bn, new_stream):
+        """A new branch from the lowest-resolution one: the conv runs on its SOURCE's stream (the source tensor is that stream's to
+        release), the new stream picks the result up through an edge."""
+        if not dataflow:
+            return cbr(name, src, conv, bn, 3, 2, True)
+        P.on(new_stream - 1)
+        t = cbr(name, src, conv, bn, 3, 2, True)
+        e = P.record()
+        P.on(new_stream)
+        P.wait(e)
+        return t
+
     ys = hr_module(bb + 'stage2.0.', xs, 2)
     # ---- transition2 / stage3 (model.py:401-407)
-    xs = [ys[0], ys[1], cbr('transition2.2', ys[-1], bb + 'transition2.2.0.0', bb + 'transition2.2.0.1', 3, 2, True)]
+    xs = [ys[0], ys[1], transition('transition2.2', ys[-1], bb + 'transition2.2.0.0', bb + 'transition2.2.0.1', 2)]
     for m in range(4):
         xs = hr_module(f'{bb}stage3.{m}.', xs, 3)
     # ---- transition3 / stage4 (model.py:409-416)
-    xs = [xs[0], xs[1], xs[2],
-          cbr('transition3.3', xs[-1], bb + 'transition3.3.0.0', bb + 'transition3.3.0.1', 3, 2, True)]
+    xs = [xs[0], xs[1], xs[2], transition('transition3.3', xs[-1], bb + 'transition3.3.0.0', bb + 'transition3.3.0.1', 3)]
     for m in range(2):
         xs = hr_module(f'{bb}stage4.{m}.', xs, 4)
     # last module emits branch 0 only -> straight into the (persistent) head input buffer
@@ -888,6 +1028,8 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
     P.head_in_buf = P.alloc(out_cstride * fs * fs, persistent=True)
     head_in = Act(P.head_in_buf, 32, fs, fs, out_cstride)
     hr_module(f'{bb}stage4.2.', xs, 1, final_out=head_in)
+    if dataflow:
+        P.join()
     return head_in
 
 

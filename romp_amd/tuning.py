@@ -20,16 +20,26 @@ def default_table_path(backbone='hrnet32', conv_math='f16x2', batch=32, workload
 
 
 def save_table(net, B, path, note=''):
+    """{layer name: kernel variant name} for the conv ops of the net's program (round 4: keyed by LAYER, so that stream markers and
+    fusions that come and go between builds do not invalidate a table; rounds 2-3 wrote a positional list `ops`)."""
     names = net.variant_names(B)
-    ops = [n if n.startswith('conv_') else '' for n in names]
+    layers = {ln: n for ln, n, op in zip(net.program.names, names, net.program.ops) if op.kind == L.OP_CONV and n.startswith('conv_')}
     with open(path, 'w') as f:
-        json.dump({'batch': int(B), 'ops': ops, 'note': note}, f, indent=0)
-    return ops
+        json.dump({'batch': int(B), 'layers': layers, 'note': note}, f, indent=0, sort_keys=True)
+    return layers
 
 
-def resolve_table(net, B, ops):
-    """names -> variant indices for THIS build (None if an op's kernel does not exist here or cannot run the op)."""
+def resolve_table(net, B, table):
+    """names -> variant indices for THIS build (None if an op's kernel does not exist here or cannot run the op).  `table`: the
+    {layer: variant} dict of save_table, or a positional list (one entry per op of the program)."""
     lib = net.lib
+    if isinstance(table, dict):
+        missing = [ln for ln, op in zip(net.program.names, net.program.ops) if op.kind == L.OP_CONV and ln not in table]
+        if missing:
+            return None, 'the table has no entry for %d conv layers of the program (%s ..)' % (len(missing), missing[0])
+        ops = [table.get(ln, '') if op.kind == L.OP_CONV else '' for ln, op in zip(net.program.names, net.program.ops)]
+    else:
+        ops = table
     if len(ops) != len(net.program.ops):
         return None, 'table has %d ops, the program %d' % (len(ops), len(net.program.ops))
     buf = C.create_string_buffer(128)
@@ -57,7 +67,7 @@ def install_table(net, B, path):
     t = json.load(open(path))
     if int(t.get('batch', -1)) != int(B):
         return False, 'table is for batch %s' % t.get('batch')
-    variants, why = resolve_table(net, B, t['ops'])
+    variants, why = resolve_table(net, B, t['layers'] if 'layers' in t else t['ops'])
     if variants is None:
         return False, why
     net.set_tuned(B, variants)

@@ -35,7 +35,7 @@ def kernel_of(variant_name):
     if fam == 'h2r':                                         # conv_h2r_kernel<P, NS, TW, KSUB>: ck = 16 * KSUB
         return 'conv_h2r_kernel<%s, %s, %s, %d>' % (mt, nt, tw, int(ck) // 16)
     if fam == 'h2k':
-        return 'conv_h2k_kernel<%s, %s>' % (mt, tw)
+        return 'conv_h2k_kernel<%s, %s, %s>' % (ks, mt, tw)
     if fam in ('h2q', 'h2s'):
         return 'conv_%s_kernel<%s, %s, %s>' % (fam, mt, nt, tw)
     if fam in ('h2p', 'h2w'):
@@ -59,7 +59,7 @@ def per_op(csv_path, counter, names):
             merged[-1][2] += v
         else:
             merged.append([d, k, v])
-    launching = [i for i, n in enumerate(names) if n not in ('fork', 'join', 'nop')]   # (nop: the first conv of a fused block)
+    launching = [i for i, n in enumerate(names) if n not in ('fork', 'join', 'nop', 'record', 'wait')]   # (nop: the first conv of a fused block)
     acc, cnt, forwards, pos, cur, skipped = defaultdict(float), defaultdict(int), 0, None, {}, []
     for d, k, v in merged:
         m = NET_KERNEL.search(k)
@@ -99,7 +99,7 @@ if __name__ == '__main__':
     ops = {}
     for i in sorted(set(fetch) & set(write)):
         ops[str(i)] = {'kernel': names[i], 'bytes': 2.0 * fetch[i] + write[i], 'fetch_bytes_x2': 2.0 * fetch[i], 'write_bytes': write[i],
-                       'algorithmic_bytes': info['bytes'][i]}
+                       'algorithmic_bytes': info['bytes'][i], 'layer': info['op_names'][i]}
     json.dump({'batch': info['batch'], 'forwards_fetch_pass': nf, 'forwards_write_pass': nw, 'ops': ops,
                'note': '2*FETCH_SIZE + WRITE_SIZE per op, mean over the profiled forwards (scripts/pmc_by_op.py)'}, open(sys.argv[4], 'w'))
     tot = sum(e['bytes'] for e in ops.values())

@@ -39,7 +39,8 @@ def main(path, skip=2):
         busy = defaultdict(int)
         for k in net:
             busy[re.sub(r'<.*', '', k[2])] += k[1] - k[0]
-        spans.append(dict(span=t1 - t0, ksum=sum(k[1] - k[0] for k in net), n=len(net), conc=dict(conc), gaps=sorted(gaps, reverse=True)[:5], busy=dict(busy),
+        allgaps = [g[0] for g in gaps]
+        spans.append(dict(allgaps=allgaps, net=net, t0=t0, span=t1 - t0, ksum=sum(k[1] - k[0] for k in net), n=len(net), conc=dict(conc), gaps=sorted(gaps, reverse=True)[:5], busy=dict(busy),
                           other=sum(k[1] - k[0] for k in ks if k not in net)))
     n = len(spans)
     avg = lambda f: sum(f(s) for s in spans) / n
@@ -47,6 +48,13 @@ def main(path, skip=2):
         n, avg(lambda s: s['span']) / 1e6, avg(lambda s: s['ksum']) / 1e6, avg(lambda s: s['n']), avg(lambda s: s['other']) / 1e6))
     for c in range(4):
         print('  %s network kernels in flight: %.3f ms' % ('3+' if c == 3 else str(c), avg(lambda s: s['conc'].get(c, 0)) / 1e6))
+    g = spans[-1]['allgaps']
+    print('  idle gaps of the last forward: %d, sum %.1f us; <2us %d, 2-5us %d, 5-10us %d, >10us %d' % (
+        len(g), sum(g) / 1e3, sum(x < 2000 for x in g), sum(2000 <= x < 5000 for x in g), sum(5000 <= x < 10000 for x in g), sum(x >= 10000 for x in g)))
+    if len(sys.argv) > 3:                                      # the last forward, kernel by kernel: start (us from the stem), duration, name
+        with open(sys.argv[3], 'w') as f:
+            for k in spans[-1]['net']:
+                f.write('%9.2f %8.2f %s\n' % ((k[0] - spans[-1]['t0']) / 1e3, (k[1] - k[0]) / 1e3, k[2]))
     print('  largest idle gaps of the last forward (us):', ', '.join('%.1f' % (g[0] / 1e3) for g in spans[-1]['gaps']))
     tot = defaultdict(float)
     for s in spans:

@@ -143,48 +143,73 @@ def test_program_matches_reference_inventory(program):
 
 
 def test_program_buffer_liveness(program):
-    """No op may read a buffer whose producer has since been overwritten: replay the program
-    symbolically, tagging each buffer with the op that last wrote it."""
-    from romp_amd.lib import OP_CONV, OP_FORK, OP_FUSESUM, OP_JOIN, OP_STEM
-    writer = {}
-    region = None          # inside FORK..JOIN: buffer -> set of streams that touched it, and how
+    """No op may read a buffer whose producer has since been overwritten, and the streams of a program may not race: replay the
+    program symbolically, tagging each buffer with the op that last wrote it; plan.stream_races is the happens-before check (stream
+    order + FORK / JOIN + the RECORD / WAIT edges of the open stage region, round 4)."""
+    from romp_amd.lib import OP_CONV, OP_FORK, OP_FUSESUM, OP_FUSEUP, OP_JOIN, OP_RECORD, OP_STEM, OP_WAIT
+    from romp_amd.plan import stream_races
+    program.op_array()
+    writer, region, recorded = {}, None, {}
     for i, op in enumerate(program.ops):
         if op.kind == OP_FORK:
             assert region is None and 1 <= op.Cin <= 3
-            region = {'n': op.Cin, 'w': {}, 'r': {}}
+            region = op.Cin
             continue
         if op.kind == OP_JOIN:
-            assert region is not None and op.Cin == region['n']
+            assert region is not None and op.Cin == region
             region = None
             continue
-        assert (op.stream == 0) if region is None else (0 <= op.stream <= region['n'])
+        assert (op.stream == 0) if region is None else (0 <= op.stream <= region)
+        if op.kind == OP_RECORD:
+            assert region is not None and op.Cin not in recorded      # event numbers are unique per program
+            recorded[op.Cin] = op.stream
+            continue
+        if op.kind == OP_WAIT:
+            assert region is not None and recorded[op.Cin] != op.stream
+            continue
         reads = []
         if op.kind in (OP_CONV, OP_STEM) and op.in_buf >= 0:
             reads.append(op.in_buf)
         if op.kind == OP_CONV and op.res_buf >= 0:
             reads.append(op.res_buf)
-        if op.kind == OP_FUSESUM:
+        if op.kind in (OP_FUSESUM, OP_FUSEUP):
             reads += [op.term_buf[k] for k in range(op.n_terms)]
         for b in reads:
             assert b in writer, 'op %d (%s) reads buffer %d before it was written' % (i, program.names[i], b)
             assert b != op.out_buf or b == program.head_in_buf, 'op %d runs in place on buffer %d' % (i, b)
-            if region is not None:
-                # concurrent streams: nobody else may have written this buffer inside the region
-                assert region['w'].get(b, {op.stream}) == {op.stream}, \
-                    'op %d (%s) on stream %d reads buffer %d written by another stream of the region' % (
-                        i, program.names[i], op.stream, b)
-                region['r'].setdefault(b, set()).add(op.stream)
         if op.out_buf >= 0:
-            if region is not None:
-                others = (region['r'].get(op.out_buf, set()) | region['w'].get(op.out_buf, set())) - {op.stream}
-                assert not others, 'op %d (%s) on stream %d writes buffer %d used by stream(s) %s in the region' % (
-                    i, program.names[i], op.stream, op.out_buf, others)
-                region['w'].setdefault(op.out_buf, set()).add(op.stream)
             writer[op.out_buf] = i
-    assert region is None
+    assert region is None and len(recorded) > 30
     assert program.head_in_buf in writer
+    assert stream_races(program) == []
     # arena stays small because of reuse: < 100 MB per image although 323 ops produce ~560 MB of activations
     assert sum(program.buf_floats) * 4 / 1e6 < 100
+
+
+@pytest.mark.parametrize('kind', ['romp_b1', 'romp_barriers', 'bev', 'resnet50'])
+def test_every_plan_kind_is_race_free(kind, monkeypatch):
+    """plan.stream_races on the other programs (Program.op_array asserts it too), and the check itself: dropping any one of a
+    sample of WAIT edges, or releasing a cross-stream tensor an epoch early, must be reported."""
+    from romp_amd import lib as L, synthetic as S
+    from romp_amd.plan import build_romp_hrnet32, stream_races
+    if kind == 'romp_barriers':
+        monkeypatch.setenv('ROMP_DATAFLOW', '0')
+    if kind == 'bev':
+        from romp_amd.bev_plan import build_bev_hrnet32
+        P = build_bev_hrnet32(S.make_bev_state_dict(0), 'cpu', 512, bf16x3='f16x2')
+    elif kind == 'resnet50':
+        from romp_amd.resnet_plan import build_romp_resnet50
+        P = build_romp_resnet50(S.make_resnet_state_dict(0), 'cpu', 512, bf16x3='f16x2')
+    else:
+        P = build_romp_hrnet32(S.make_romp_state_dict(0), 'cpu', 512, bf16x3='f16x2', **(dict(split_k_items=128) if kind == 'romp_b1' else {}))
+    P.op_array()
+    assert stream_races(P) == []
+    waits = [i for i, o in enumerate(P.ops) if o.kind == L.OP_WAIT]
+    assert (len(waits) == 0) == (kind in ('romp_barriers', 'resnet50'))
+    for i in waits[::5]:
+        P.ops[i].kind = L.OP_NOP
+        assert stream_races(P), 'dropping the wait at op %d went unnoticed' % i
+        P.ops[i].kind = L.OP_WAIT
 
 
 def test_conv_describe_every_op(program):
