@@ -23,7 +23,7 @@ names = net.variant_names(B)
 P = net.program
 rows = []
 for i, (nm, t) in enumerate(zip(names, ms)):
-    if nm in ('fork', 'join'):
+    if nm in ('fork', 'join', 'record', 'wait'):
         continue
     op = P.ops[i]
     if P.names[i].startswith('bev.'):
