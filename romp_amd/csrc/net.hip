@@ -296,22 +296,27 @@ static int run_lane(romp_net* n, const float* image, int B, float* center, float
 static int build_graph(romp_net* n, const float* image, int B, float* center, float* params, int lane, int b0, size_t first_op, bool whole,
                        hipGraph_t* out) {
     typedef std::vector<hipGraphNode_t> Nodes;
-    hipGraph_t G = nullptr;
-    ROMP_HIP_CHECK(hipGraphCreate(&G, 0));
+    struct Owned {                                             // a graph that dies with its scope unless released
+        hipGraph_t g = nullptr;
+        ~Owned() { if (g) hipGraphDestroy(g); }
+    };
+    Owned top;
+    ROMP_HIP_CHECK(hipGraphCreate(&top.g, 0));
+    hipGraph_t G = top.g;
     Nodes frontier[4];                                         // per stream: the nodes its next op depends on
     std::map<int, Nodes> events;
     auto merge = [](Nodes& into, const Nodes& from) {
         for (hipGraphNode_t x : from)
             if (std::find(into.begin(), into.end(), x) == into.end()) into.push_back(x);
     };
-    auto fail = [&](int rc) { hipGraphDestroy(G); return rc; };
     auto add_op = [&](int s, auto&& body) -> int {             // capture `body` on the scratch stream, move its nodes behind frontier[s]
-        hipGraph_t g1 = nullptr;
+        Owned one;
         ROMP_HIP_CHECK(hipStreamBeginCapture(n->scratch, hipStreamCaptureModeThreadLocal));
         const int rc = body(n->scratch);
-        const hipError_t e = hipStreamEndCapture(n->scratch, &g1);
-        if (rc) { if (g1) hipGraphDestroy(g1); return rc; }
+        const hipError_t e = hipStreamEndCapture(n->scratch, &one.g);
+        if (rc) return rc;
         ROMP_HIP_CHECK(e);
+        hipGraph_t g1 = one.g;
         size_t cnt = 0;
         ROMP_HIP_CHECK(hipGraphGetNodes(g1, nullptr, &cnt));
         if (cnt) {
@@ -334,7 +339,6 @@ static int build_graph(romp_net* n, const float* image, int B, float* center, fl
                     ROMP_HIP_CHECK(hipGraphAddMemsetNode(&nn, G, frontier[s].data(), frontier[s].size(), &mp));
                 } else {
                     set_error("build_graph: an op captured a node of type %d", (int)type);
-                    hipGraphDestroy(g1);
                     return ROMP_EHIP;
                 }
                 frontier[s].assign(1, nn);
@@ -346,7 +350,6 @@ static int build_graph(romp_net* n, const float* image, int B, float* center, fl
                 }
             }
         }
-        ROMP_HIP_CHECK(hipGraphDestroy(g1));
         return ROMP_OK;
     };
     conv_set_sat_counter(n->sat, n->sat_checked);
@@ -379,8 +382,9 @@ static int build_graph(romp_net* n, const float* image, int B, float* center, fl
         }
     }
     n->wg_cap = cap;
-    if (rc) return fail(rc);
-    *out = G;
+    if (rc) return rc;
+    *out = top.g;
+    top.g = nullptr;
     return ROMP_OK;
 }
 

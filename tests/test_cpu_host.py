@@ -506,3 +506,32 @@ def test_hrnet_program_fusions_are_the_documented_ones(monkeypatch):
     assert kinds() == (0, 0, 3, 0, 23, 3)
     monkeypatch.setenv('ROMP_FUSE_SEAMS', '0')
     assert kinds() == (0, 0, 0, 0, 23, 0)
+
+
+@pytest.mark.parametrize('cfg', [('romp', 'hrnet32', 32), ('romp', 'hrnet32', 128), ('romp', 'bev-hrnet32', 32), ('romp', 'resnet50', 32)],
+                         ids=lambda c: '%s_%s_b%d' % c)
+def test_committed_variant_tables_resolve(cfg):
+    """romp_amd/tune/*.json are keyed by layer name: each must have an entry for every conv layer of today's program of its
+    configuration, and every named kernel must exist in this build and be able to run its layer (romp_conv_describe needs no GPU).
+    A plan change that renames layers, or a variant dropped from the library, fails here -- not as a silent fall-back to the
+    heuristics on the GPU box."""
+    import json, types
+    from romp_amd import lib as L, synthetic as S, tuning
+    workload, backbone, B = cfg
+    if backbone == 'hrnet32':
+        from romp_amd.plan import build_romp_hrnet32
+        P = build_romp_hrnet32(S.make_romp_state_dict(0), 'cpu', 512, bf16x3='f16x2')
+    elif backbone == 'bev-hrnet32':
+        from romp_amd.bev_plan import build_bev_hrnet32
+        P = build_bev_hrnet32(S.make_bev_state_dict(0), 'cpu', 512, bf16x3='f16x2')
+    else:
+        from romp_amd.resnet_plan import build_romp_resnet50
+        P = build_romp_resnet50(S.make_resnet_state_dict(0), 'cpu', 512, bf16x3='f16x2')
+    P.op_array()
+    t = json.load(open(tuning.default_table_path(backbone, 'f16x2', B, workload)))
+    assert t['batch'] == B and 'layers' in t
+    convs = [n for n, o in zip(P.names, P.ops) if o.kind == L.OP_CONV]
+    assert sorted(convs) == sorted(t['layers']), set(convs) ^ set(t['layers'])
+    variants, why = tuning.resolve_table(types.SimpleNamespace(lib=L.load(), program=P), B, t['layers'])
+    assert variants is not None, why
+    assert sum(v >= 0 for v in variants) == len(convs)
