@@ -482,20 +482,28 @@ def bench_bev(args, dev):
         res['roofline'] = roof
         res['kernel_classes'] = classes
     if not args.no_cpu_baseline:
-        from oracle import bev_oracle as BO
+        from oracle import bev_oracle as BO, ref_cpu
         torch.set_num_threads(usable_cores())
         img1 = images[:1].cpu()
         sd = dict(sd)
-        sd['coordmap_3d'] = BO.coordmap_3d()                     # the oracle's constant buffer (bev/model.py:9-17)
+        if ref_cpu.bev_available():      # the reference's own BEVv1 (oracle/_ref/bev/model.pyc: simple_romp/bev/model.py:104-250), PyTorch-CPU
+            ref = ref_cpu.ReferenceBev(sd, mid)
+            run, kind = (lambda: ref(img1.clone())), 'reference'
+            what = ('the reference itself: BEVv1.forward (simple_romp/bev/model.py:232-250: network + 3-D parse + regression), PyTorch-CPU '
+                    'float32, byte-compiled from /root/reference into oracle/_ref/bev')
+        else:
+            sd['coordmap_3d'] = BO.coordmap_3d()                 # the oracle's constant buffer (bev/model.py:9-17)
+            run, kind = (lambda: BO.bev_forward(sd, img1, mid)), 'port'
+            what = 'the torch-CPU oracle restatement (network + 3-D parse + regression; oracle/_ref/bev is not staged on this box)'
         t0 = time.time()
-        BO.bev_forward(sd, img1, mid)
+        run()
         warm = time.time() - t0
         t0, k = time.time(), 0
         while warm < args.cpu_seconds / 2 and time.time() - t0 < args.cpu_seconds and k < 8:
-            BO.bev_forward(sd, img1, mid); k += 1
+            run(); k += 1
         cdt = (time.time() - t0) if k else warm
-        res['cpu_baseline'] = dict(value=round(max(k, 1) / cdt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                                   sample='%d single-image BEV forwards (network + 3-D parse + regression) of the torch-CPU oracle restatement' % max(k, 1))
+        res['cpu_baseline'] = dict(value=round(max(k, 1) / cdt, 3), unit='images/s', cores=torch.get_num_threads(), kind=kind,
+                                   sample='%d single-image BEV forwards of %s' % (max(k, 1), what))
     print(json.dumps(res), flush=True)
 
 

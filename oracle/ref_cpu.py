@@ -51,6 +51,59 @@ def load():
     return mods
 
 
+BEV_DIR = os.path.join(HERE, '_ref', 'bev')
+BEV_MODS = ('post_parser', 'model')
+
+
+def bev_available():
+    return available() and all(os.path.exists(os.path.join(BEV_DIR, m + '.pyc')) for m in BEV_MODS)
+
+
+def load_bev():
+    """-> dict of the reference's BEV modules (package `bev`, on top of the staged `romp` package), or None when not staged."""
+    if not bev_available():
+        return None
+    load()
+    if 'bev.model' in sys.modules and getattr(sys.modules['bev.model'], '__romp_ref__', False):
+        return {m: sys.modules['bev.' + m] for m in BEV_MODS}
+    pkg = types.ModuleType('bev')
+    pkg.__path__ = [BEV_DIR]
+    sys.modules['bev'] = pkg
+    mods = {}
+    for name in BEV_MODS:
+        path = os.path.join(BEV_DIR, name + '.pyc')
+        loader = importlib.machinery.SourcelessFileLoader('bev.' + name, path)
+        spec = importlib.util.spec_from_loader('bev.' + name, loader, origin=path)
+        m = importlib.util.module_from_spec(spec)
+        m.__romp_ref__ = True
+        sys.modules['bev.' + name] = m
+        loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+class ReferenceBev:
+    """BEVv1 of the reference (simple_romp/bev/model.py:104-250: backbone, coarse-to-fine 3-D localisation, 3-D centre-map parse,
+    mesh parameter regression) on the CPU, holding the caller's (synthetic) weights."""
+
+    def __init__(self, state_dict, center_thresh):
+        ref = load_bev()
+        assert ref is not None, 'oracle/_ref/bev is not staged (make -C oracle in the build container)'
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):                         # (the constructors print their settings)
+            self.net = ref['model'].BEVv1(center_thresh=center_thresh).eval()
+        sd = {k: v for k, v in state_dict.items() if k != 'coordmap_3d'}        # the module's own constant buffer (model.py:127-128)
+        missing = self.net.load_state_dict(sd, strict=False)
+        assert all(k.endswith('num_batches_tracked') or k == 'coordmap_3d' for k in missing.missing_keys) and not missing.unexpected_keys, missing
+
+    @torch.no_grad()
+    def __call__(self, images):
+        """images (B,512,512,3) float 0..255 (CPU) -> BEVv1.forward's dict, or None."""
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            return self.net(images)
+
+
 class ReferencePipeline:
     """ROMPv1 + CenterMap parser + SMPL of the reference, holding the caller's (synthetic) weights."""
 
