@@ -867,7 +867,7 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
     # Round 4: the stages form ONE open fork .. join region with point-to-point edges (ROMP_OP_RECORD / ROMP_OP_WAIT) instead of two
     # full fork/join barriers per module: branch j lives on stream j from transition1 to the last module; a fuse output waits for
     # exactly the tensors it sums; the next module's branch follows its own fuse output in stream order.  A cross-stream hand-over
-    # costs 5-10 us on this runtime (profiles/r04_b1_timeline.txt) and a barrier idles every stream until the slowest branch is done.
+    # costs 5-10 us on this runtime (profiles/r04_notes.md, section 8) and a barrier idles every stream until the slowest branch is done.
     # ROMP_DATAFLOW=0: the barrier form of rounds 1-3 (A/B runs).
     dataflow = P.parallel and os.environ.get('ROMP_DATAFLOW', '1') != '0'
     P.fork(3 if dataflow else 1)
@@ -893,12 +893,17 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
         channels when there are several (round 4: towards outputs j+1, j+2, j+3 they all read the same tensor; it is now read
         once: [no-ReLU channels of the chain that ends here | ReLU channels of the longer chains], romp_op.relu_from) -- and the
         1x1 up-convs towards the outputs above (model.py:186-196).  Region 2 (one stream per output i): the rest of the chains
-        and the sum."""
+        and the sum.
+
+        `dataflow` (round 4, the default): no fork / join here -- the caller holds ONE region open over all stages.  Stream j
+        records an event behind its stride-2 convs and one behind its up-convs; output i waits for the first kind from the branches
+        below it and the second kind from those above it; what another stream reads is released an epoch late (Program.free_later),
+        what only its own stream touches at once."""
         nb = len(xs)
         xs = list(xs)
         ch = [x.C for x in xs]
         first, ups, temps = {}, {}, []                            # (i, j) -> Act
-        ev_s2, ev_up, own = {}, {}, {}                            # dataflow: events after branch j's stride-2 / up convs; own[i]: stream i's private temporaries
+        ev_s2, ev_up = {}, {}                                     # dataflow: the events after branch j's stride-2 convs / up-convs
         if not dataflow:
             P.fork(nb - 1)
         for br in range(nb):
