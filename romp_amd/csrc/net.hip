@@ -4,8 +4,9 @@
 // romp_op; this file owns the activation arena (NHWC float32, sized for max_batch, resident in HBM
 // for the life of the context), the per-op work queues of the persistent conv kernels, the
 // per-batch-size kernel-variant table filled by romp_net_autotune, and replays the list on the
-// caller's stream -- eagerly, or from a hipGraph captured per (batch, output pointers; the stem runs eagerly in front of it) so that the
-// ~330 dependent launches of one forward cost one graph launch on the host.
+// caller's stream and up to three side streams (FORK / JOIN regions, RECORD / WAIT edges inside them) -- eagerly, or from a hipGraph
+// per (batch, output pointers; the stem runs eagerly in front of it) that build_graph assembles node by node with the program's
+// dependencies, so that the ~220-330 dependent launches of one forward cost one graph launch on the host.
 #include "common.h"
 #include "conv_common.h"   // h2_unpack (range scan)
 #include <algorithm>
