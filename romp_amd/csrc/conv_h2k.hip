@@ -1,4 +1,4 @@
-// conv_h2k.hip -- 3x3 stride-1 convolution on the f16x2 split with the INPUT CHANNELS split across the waves of a workgroup ("h2k",
+// conv_h2k.hip -- 3x3 (stride 1 | 2) and 1x1 convolution on the f16x2 split with the INPUT CHANNELS split across the waves of a workgroup ("h2k",
 // round 4): the single-image form of conv_h2r.hip.
 //
 // At batch 1 the deep layers have few pixels (32^2 x 128, 16^2 x 256 channels): a 64-pixel x 128-channel workgroup tile is 16 work items
@@ -18,10 +18,10 @@
 
 namespace romp {
 
-template <int KS, int P, int TW>                               // KS = 3: 3x3, 1: 1x1 (the 1x1 up-convs of a single-image plan)
+template <int KS, int S, int P, int TW>                        // KS = 3: 3x3, 1: 1x1 (the 1x1 up-convs of a single-image plan); S: stride 1 | 2
 struct KCfg {
     static constexpr int NWV = 4, TAPS = KS * KS;
-    using C = ConvCfg<KS, 1, P, 1, TW, 16, 1>;                 // TH = P * (32 / TW) rows, NW = 32 channels
+    using C = ConvCfg<KS, S, P, 1, TW, 16, 1>;                 // TH = P * (32 / TW) rows, NW = 32 channels
     static constexpr int CG = (C::HC + 3) / 4;                 // 4-pixel column groups per haloed row
     static constexpr int RSU = CG * 16;                        // 16-byte units per haloed row
     static constexpr int NIW = (C::HR * RSU + 63) / 64;        // DMA pieces (wave-instructions of 1 KiB) of ONE wave's chunk
@@ -30,7 +30,7 @@ struct KCfg {
     static constexpr int OFF_R = 2 * STAGE_BYTES;              // reduction tiles: [block][wave][channel quad g4][lane] float4
     static constexpr int RED_BYTES = P * NWV * 4 * 64 * 16;
     static constexpr int LDS_BYTES = OFF_R + RED_BYTES + 16;
-    static_assert(KS == 1 || KS == 3, "1x1 or 3x3");
+    static_assert((KS == 1 || KS == 3) && (S == 1 || S == 2), "1x1 or 3x3, stride 1 or 2");
     static_assert((C::HR - 1) * RSU * 16 + RSU * 16 < 65536, "fragment read offsets are ds_read immediates");
 };
 
@@ -43,10 +43,10 @@ struct KStage {                 // wave-uniform description of one of this wave'
     int iy0, ix0, c0;
 };
 
-template <int KS, int P, int TW>
+template <int KS, int S, int P, int TW>
 __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
     if (p.dbg & 32) return;
-    using X = KCfg<KS, P, TW>;
+    using X = KCfg<KS, S, P, TW>;
     constexpr int TAPS = X::TAPS;
     using C = typename X::C;
     using frag = f16x8;
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
         d.c0 = (s * NWV + wave) * 16;
         d.in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs + d.c0;
         d.wg = p.wh + (size_t)it.g * (TAPS * cin16 * 4 * p.cout_pad) + (d.c0 >> 4) * 4 * p.cout_pad + it.n0;
-        d.iy0 = it.ty * C::TH - p.pad_h;
-        d.ix0 = it.tx * TW - p.pad_w;
+        d.iy0 = it.ty * C::TH * S - p.pad_h;
+        d.ix0 = it.tx * TW * S - p.pad_w;
         return d;
     };
     auto issue_piece = [&](int k, const KStage& d, int buf) {
@@ -102,15 +102,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
         wreg[tap][1] = __builtin_bit_cast(frag, wp[w_pc]);
         wp += w_tap;
     };
-    int xa[KS][2];                                             // fragment addresses of block 0: pixel (row, col + dx), unit 2 lh + piece
-    {
-        const int prow = li / TW, pcol = li % TW;
+    int xa[KS][2];                                             // fragment addresses of block 0: input pixel (S row, S col + dx), unit 2 lh + piece
+    {                                                          // (stride 2 reads every other pixel of the rotated layout: two-way bank conflicts,
+        const int prow = li / TW, pcol = li % TW;              //  which a single image's latency-bound launches do not notice)
 #pragma unroll
         for (int dx = 0; dx < KS; ++dx)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
-                const int col = pcol + dx, w = lh * 2 + pc;
-                xa[dx][pc] = (prow * X::RSU + (col >> 2) * 16 + (col & 3) + 4 * ((w + (col >> 2)) & 3)) * 16;
+                const int col = pcol * S + dx, w = lh * 2 + pc;
+                xa[dx][pc] = (prow * S * X::RSU + (col >> 2) * 16 + (col & 3) + 4 * ((w + (col >> 2)) & 3)) * 16;
             }
     }
 
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
                 for (int j = 0; j < P; ++j)
 #pragma unroll
                     for (int pc = 0; pc < 2; ++pc)
-                        x[j][pc] = *reinterpret_cast<const frag*>(sA + xa[dx][pc] + (j * C::RPB + dy) * (X::RSU * 16));
+                        x[j][pc] = *reinterpret_cast<const frag*>(sA + xa[dx][pc] + (j * C::RPB * S + dy) * (X::RSU * 16));
 #pragma unroll
                 for (int j = 0; j < P; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap][1], x[j][0], acc[j], 0, 0, 0);
 #pragma unroll
@@ -260,10 +260,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
 }
 
 // math 10: the input channels split across the workgroup's waves; `ck` = 64 (a super-stage)
-#define ROMP_CONV_VARIANT_H2K(KS, P, TW)                                                               \
-    { KS, 1, P, 1, TW, 64, conv_h2k_kernel<KS, P, TW>, KCfg<KS, P, TW>::LDS_BYTES, KCfg<KS, P, TW>::C::TH, 0, 0, 10, 256 }
+#define ROMP_CONV_VARIANT_H2K(KS, S, P, TW)                                                            \
+    { KS, S, P, 1, TW, 64, conv_h2k_kernel<KS, S, P, TW>, KCfg<KS, S, P, TW>::LDS_BYTES, KCfg<KS, S, P, TW>::C::TH, 0, 0, 10, 256 }
 
-static ConvVariant kVariantsH2k[] = { ROMP_CONV_VARIANT_H2K(3, 1, 16), ROMP_CONV_VARIANT_H2K(3, 2, 16), ROMP_CONV_VARIANT_H2K(1, 1, 16) };
+static ConvVariant kVariantsH2k[] = { ROMP_CONV_VARIANT_H2K(3, 1, 1, 16), ROMP_CONV_VARIANT_H2K(3, 1, 2, 16), ROMP_CONV_VARIANT_H2K(1, 1, 1, 16),
+                                      ROMP_CONV_VARIANT_H2K(3, 2, 1, 16) };
 ConvVariant* conv_variants_h2k(int* n) { *n = (int)(sizeof(kVariantsH2k) / sizeof(kVariantsH2k[0])); return kVariantsH2k; }
 
 }  // namespace romp

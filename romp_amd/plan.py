@@ -653,7 +653,8 @@ class Program:
         if self.split_k_items <= 0 or ksize not in (1, 3) or Wo % 16 or cout % 8:
             return 1
         import os
-        if (self.f16x2 and stride == 1 and cin % 64 == 0 and cout % 32 == 0 and os.environ.get('ROMP_KSPLIT_WG', '1') != '0'):
+        if (self.f16x2 and (stride == 1 or (ksize == 3 and os.environ.get('ROMP_KSPLIT_S2', '1') != '0')) and cin % 64 == 0 and cout % 32 == 0 and
+                os.environ.get('ROMP_KSPLIT_WG', '1') != '0'):
             # round 4: csrc/conv_h2k.hip splits the input channels across the WAVES of a workgroup and reduces in LDS -- the layer
             # stays one conv op (no float32 partial tensors, no ksum launch); the autotuner picks it wherever the tensors are H2
             return 1

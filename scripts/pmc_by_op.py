@@ -35,7 +35,7 @@ def kernel_of(variant_name):
     if fam == 'h2r':                                         # conv_h2r_kernel<P, NS, TW, KSUB>: ck = 16 * KSUB
         return 'conv_h2r_kernel<%s, %s, %s, %d>' % (mt, nt, tw, int(ck) // 16)
     if fam == 'h2k':
-        return 'conv_h2k_kernel<%s, %s, %s>' % (ks, mt, tw)
+        return 'conv_h2k_kernel<%s, %s, %s, %s>' % (ks, s, mt, tw)
     if fam in ('h2q', 'h2s'):
         return 'conv_%s_kernel<%s, %s, %s>' % (fam, mt, nt, tw)
     if fam in ('h2p', 'h2w'):

@@ -645,15 +645,15 @@ def test_translation_lsq_vs_reference_fixture(dev, golden_dir):
 def test_net_split_k_single_image(dev, golden_dir, conv_math):
     """Single-image nets (max_batch <= 2) lower the layers with few pixels and many input channels as split-K convs (grouped
     conv over input-channel slices -> float32 partials -> ksum with the layer's epilogue); with the f16x2 kernels on offer the deep
-    stride-1 layers stay ONE conv instead and csrc/conv_h2k.hip splits their input channels across the waves of a workgroup (round 4:
-    171 -> 11 ksum launches, the stride-2 convs; the tuned single-image table must actually pick conv_h2k for them).  Same gates as every other plan:
+    layers stay ONE conv instead and csrc/conv_h2k.hip splits their input channels across the waves of a workgroup (round 4:
+    171 -> 0 ksum launches; the tuned single-image table must actually pick conv_h2k for them).  Same gates as every other plan:
     1e-4 against the reference fixture (B=1) and the oracle (B=2)."""
     from romp_amd.net import RompNet
     from romp_amd.lib import OP_KSUM
     sd = O.make_romp_state_dict(0)
     net = RompNet(sd, dev, max_batch=2, bf16x3=conv_math)
     n_ksum = sum(o.kind == OP_KSUM for o in net.program.ops)
-    assert net.split_k == 128 and (n_ksum > 150 if conv_math == 'f32' else 5 < n_ksum < 40), n_ksum
+    assert net.split_k == 128 and (n_ksum > 150 if conv_math == 'f32' else n_ksum == 0), n_ksum
     if conv_math == 'f16x2':
         net.autotune(1, iters=1)
         assert sum('conv_h2k' in n for n in net.variant_names(1)) > 100, 'the deep 3x3 layers of a single image belong on conv_h2k'
