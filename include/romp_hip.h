@@ -169,7 +169,8 @@ int  romp_net_write_buffer(romp_net* net, int buf, const float* src, int64_t n_f
 int  romp_net_set_mode(romp_net* net, int mode);
 /* 1 (default): independent HRNet branches (FORK/JOIN regions) run on side HIP streams. */
 int  romp_net_set_streams(romp_net* net, int enable);
-/* 1: capture the layer program into a hipGraph per (B, pointers) and replay it. */
+/* 1: turn the layer program into a hipGraph per (B, pointers) and replay it (built node by node from single-op captures with the
+ * program's own dependencies: csrc/net.hip build_graph).  Needs a non-default stream. */
 int  romp_net_set_graph(romp_net* net, int enable);
 /* Measure every valid kernel variant of every conv layer at batch B (HIP events on `stream`,
  * `iters` timed runs each) and use the fastest from now on for that batch size. */
