@@ -535,3 +535,21 @@ def test_committed_variant_tables_resolve(cfg):
     variants, why = tuning.resolve_table(types.SimpleNamespace(lib=L.load(), program=P), B, t['layers'])
     assert variants is not None, why
     assert sum(v >= 0 for v in variants) == len(convs)
+
+
+@pytest.mark.parametrize('env', [{'ROMP_MERGE_S2': '0'}, {'ROMP_FUSEUP': 'all'}, {'ROMP_FUSE_BLOCKS': 'all'}, {'ROMP_FUSE_SEAMS': 'all'},
+                                 {'ROMP_KSPLIT_WG': '0'}, {'ROMP_MERGE_S2': '0', 'ROMP_FUSEUP': '0', 'ROMP_FUSE_BLOCKS': '0'}],
+                         ids=lambda e: '+'.join('%s=%s' % kv for kv in e.items()))
+def test_plan_switches_stay_race_free(env, monkeypatch):
+    """The A/B switches of DESIGN.md change which ops exist and which buffers they share: every combination used in the notes must
+    still lower to a program whose streams do not race (Program.op_array asserts it; this keeps the assertion exercised)."""
+    from romp_amd import synthetic as S
+    from romp_amd.plan import build_romp_hrnet32, stream_races
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sd = S.make_romp_state_dict(0)
+    for kw in (dict(split_k_items=128), dict()):
+        for math in ('f16x2', False):
+            P = build_romp_hrnet32(sd, 'cpu', 512, bf16x3=math, **kw)
+            P.op_array()
+            assert stream_races(P) == []
