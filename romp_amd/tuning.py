@@ -2,8 +2,9 @@
 tests of one build all run the same kernels (the autotuner's near-ties used to flip the "dominant" kernel between
 a bench run and the PMC passes quoted beside it).
 
-A table is JSON: {"batch": B, "ops": [kernel variant name per op, "" for ops that are not convs], "note": ...}.  Names
-(`conv_h2r_k3s1_mt2_nt2_tw16_ck16`) survive additions to the variant list of the library, indices do not.  The committed
+A table is JSON: {"batch": B, "layers": {layer name: kernel variant name} for the conv ops, "note": ...} (rounds 2-3: a positional
+list "ops", still read).  Variant names (`conv_h2r_k3s1_mt2_nt2_tw16_ck16`) survive additions to the variant list of the library,
+indices do not; layer names survive stream markers and fusions that move op indices.  The committed
 tables live in romp_amd/tune/; `default_table_path()` names the one for a (backbone, conv_math, batch) configuration.
 """
 import ctypes as C
