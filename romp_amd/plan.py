@@ -506,7 +506,8 @@ def fuse_basic_blocks(P):
             # the row-pipelined kernels (conv_h2c.hip) read their weights per wave (16 output channels each).  32 channels: batch plans only
             # (two workgroups per CU; a single image's tiles are better off on conv_h2b.hip's kernel: 2.10 vs 2.15 ms at B = 1)
             # ROMP_BBLOCK32=v1: conv_h2b.hip's kernel everywhere (A/B runs); anything else: the default
-            if C_ == 64 or (os.environ.get('ROMP_BBLOCK32', 'r') != 'v1' and not getattr(P, 'split_k_items', 0)):
+            # ROMP_BBLOCK32=r1: the row-pipelined kernel in single-image plans too (A/B runs)
+            if C_ == 64 or (os.environ.get('ROMP_BBLOCK32', 'r') != 'v1' and not getattr(P, 'split_k_items', 0)) or os.environ.get('ROMP_BBLOCK32') == 'r1':
                 by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
                 for o in (a, b):
                     t = pack_h2_wave16(by_ptr[o.weight_h2].view(9, C_ // 16, 2, 2, C_, 8))
