@@ -35,6 +35,9 @@ int main(int argc, char** argv) {
     int32_t size = 0, n_ops = 0;
     int64_t cf = 0, pf = 0;
     CHECK(romp_net_plan_info(net, &size, &cf, &pf, &n_ops));
+    int32_t split_k_items = 0;
+    CHECK(romp_net_plan_kind(net, &split_k_items));
+    if (split_k_items > 0 && B > 2) fprintf(stderr, "note: %s is a single-image plan (split_k_items %d); export a batch plan for B = %d\n", argv[1], split_k_items, B);
     const size_t img_floats = (size_t)B * size * size * 3;
     std::vector<float> frames(img_floats);
     FILE* f = fopen(argv[2], "rb");

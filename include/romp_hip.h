@@ -195,6 +195,10 @@ int  romp_net_set_tuned(romp_net* net, int B, const int32_t* variants, int n_ops
  * recorded in the file (0 for a net that was not loaded from a file), and the op count. */
 int  romp_net_load(romp_net** out, const char* path, int max_batch);
 int  romp_net_plan_info(romp_net* net, int32_t* input_size, int64_t* center_floats, int64_t* params_floats, int32_t* n_ops);
+/* The KIND of plan the file holds (plan-file version 2 header): *split_k_items > 0 = a single-image plan (the layers with few
+ * pixels were lowered with their input channels split until they had that many work items: meant for max_batch <= 2, correct but
+ * slow beyond), 0 = a batch plan, or a net that was not loaded from a file. */
+int  romp_net_plan_kind(romp_net* net, int32_t* split_k_items);
 /* Time a forward per op (HIP events on `stream` around every op, ops serialised on that stream): ms_out_host[n_ops] = the
  * median of `iters` passes. */
 int  romp_net_profile(romp_net* net, const float* image_nhwc, int B, float* center_maps,

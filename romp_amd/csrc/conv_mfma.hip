@@ -57,8 +57,10 @@ static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers wit
 static int* g_cu_slots = nullptr;           // ROMP_CONV_SKEW experiment: per-CU arrival counters
 static int g_skew = 0;
 static float* g_zero = nullptr;             // 256 bytes of zeros (out-of-image lanes of LDS-DMA pixel fetches)
-static int* g_sat = nullptr;                // saturation counter of the net being run (conv_set_sat_counter), or nullptr
-static bool g_sat_checked = false;          // run the counting builds of the fused-block kernels (romp_net_range_scan, ROMP_CHECK_FINITE=1)
+// Per HOST THREAD: the executor names its net's counter / cap right before it enqueues on that thread, so two nets driven from two
+// threads (RompNet.twin, ROMP_PIPE_NETS=2, a host with one net per thread) never see each other's values.
+static thread_local int* g_sat = nullptr;   // saturation counter of the net being run (conv_set_sat_counter), or nullptr
+static thread_local bool g_sat_checked = false;          // run the counting builds of the fused-block kernels (romp_net_range_scan, ROMP_CHECK_FINITE=1)
 static unsigned long long* g_trace = nullptr;   // env ROMP_CONV_TRACE=1: per-wave phase stamps of the most recent split-precision conv launch
 
 static const int kMaxLds = 160 * 1024;
@@ -95,7 +97,7 @@ static int ensure_attrs() {
 // The executor (net.hip) names the running net's counter before it enqueues; every launcher copies it into its parameters.
 void conv_set_sat_counter(int* counter, bool checked_fused) { g_sat = counter; g_sat_checked = checked_fused; }
 int* conv_sat_counter() { return g_sat; }
-static int g_fused_cap = 0;                 // workgroups per CU the fused kernels may take (0: all they can); set with the net's wg_cap
+static thread_local int g_fused_cap = 0;    // workgroups per CU the fused kernels may take (0: all they can); set with the net's wg_cap
 void conv_set_wg_cap(int cap) { g_fused_cap = cap; }
 int conv_wg_cap() { return g_fused_cap; }
 bool conv_sat_checked() { return g_sat_checked; }

@@ -75,6 +75,7 @@ struct romp_net {
     std::vector<char> plan_host;
     int32_t plan_input_size = 0;
     int64_t plan_center_floats = 0, plan_params_floats = 0;
+    int32_t plan_split_k_items = 0;      // plan kind recorded in the file: > 0 = single-image plan (export.py)
 };
 
 // Arena buffers are batch-major: image b of buffer `buf` starts at b * buf_floats[buf].  `b0` is the
@@ -837,7 +838,8 @@ int romp_net_range_scan(romp_net* n, const float* image, int B, float* center, f
     if (rc == ROMP_OK && (hipMemcpyAsync(&sat_before, n->sat, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
         set_error("range scan: reading the saturation counter failed"); rc = ROMP_EHIP;
     }
-    const std::vector<int>* tv = tuned_for(n, B);
+    // the kernels the FORWARD of this batch runs: with two lanes active every kernel sees B / 2 images and the table measured for that
+    const std::vector<int>* tv = tuned_for(n, lanes_active(n, B) ? B / 2 : B);
     conv_set_sat_counter(n->sat, true);
     if (rc == ROMP_OK) rc = reset_queues(n, st);
     for (size_t i = 0; i < nops && rc == ROMP_OK; ++i) {
@@ -997,6 +999,7 @@ int romp_net_tuned_variant(romp_net* n, int B, int op_index) {
 struct PlanHeader {
     char magic[8];                      // "ROMPPLAN"
     uint32_t version, abi, n_ops, n_bufs, n_inits, n_tuned, input_size, op_bytes;
+    uint32_t split_k_items, flags;      // version 2: the KIND of plan -- > 0: single-image plan lowered with this work-item target; flags reserved (0)
     uint64_t center_floats, params_floats, dev_bytes, host_bytes;
 };
 struct PlanInit { int32_t buf; int32_t pad; uint64_t floats; uint64_t dev_off; };   // per-image content, replicated for every image
@@ -1017,7 +1020,7 @@ int romp_net_load(romp_net** out, const char* path, int max_batch) {
     }
     PlanHeader h;
     memcpy(&h, file.data(), sizeof(h));
-    ROMP_REQUIRE(memcmp(h.magic, "ROMPPLAN", 8) == 0 && h.version == 1, "romp_net_load: %s is not a version-1 plan file", path);
+    ROMP_REQUIRE(memcmp(h.magic, "ROMPPLAN", 8) == 0 && h.version == 2, "romp_net_load: %s is not a version-2 plan file", path);
     ROMP_REQUIRE(h.abi == ROMP_ABI_VERSION && h.op_bytes == sizeof(romp_op), "romp_net_load: plan was written for ABI %u (romp_op %u bytes), this library is ABI %d (%zu bytes)",
                  h.abi, h.op_bytes, ROMP_ABI_VERSION, sizeof(romp_op));
     size_t at = sizeof(PlanHeader);
@@ -1071,6 +1074,7 @@ int romp_net_load(romp_net** out, const char* path, int max_batch) {
     n->plan_input_size = (int32_t)h.input_size;
     n->plan_center_floats = (int64_t)h.center_floats;
     n->plan_params_floats = (int64_t)h.params_floats;
+    n->plan_split_k_items = (int32_t)h.split_k_items;
     for (const PlanInit& in : inits) {
         if (in.buf < 0 || in.buf >= (int)h.n_bufs || buf_floats[in.buf] < 0 || in.floats > (uint64_t)buf_floats[in.buf] ||
             in.dev_off > h.dev_bytes || in.floats > (h.dev_bytes - in.dev_off) / 4) {      // (no sum that could wrap)
@@ -1100,6 +1104,12 @@ int romp_net_plan_info(romp_net* n, int32_t* input_size, int64_t* center_floats,
     if (center_floats) *center_floats = n->plan_center_floats;
     if (params_floats) *params_floats = n->plan_params_floats;
     if (n_ops) *n_ops = (int32_t)n->ops.size();
+    return ROMP_OK;
+}
+
+int romp_net_plan_kind(romp_net* n, int32_t* split_k_items) {
+    ROMP_REQUIRE(n && split_k_items, "romp_net_plan_kind: bad arguments");
+    *split_k_items = n->plan_split_k_items;
     return ROMP_OK;
 }
 

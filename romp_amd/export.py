@@ -8,8 +8,9 @@ by ``autotune`` -- and ``romp_net_load(path, max_batch)`` (C ABI; ``RompNet.from
 
 Layout (little endian; the C reader is ``csrc/net.hip`` ``romp_net_load``)::
 
-    PlanHeader   magic "ROMPPLAN", u32 version = 1, abi, n_ops, n_bufs, n_inits, n_tuned, input_size, sizeof(romp_op),
-                 u64 center_floats, params_floats (per image), dev_bytes, host_bytes
+    PlanHeader   magic "ROMPPLAN", u32 version = 2, abi, n_ops, n_bufs, n_inits, n_tuned, input_size, sizeof(romp_op),
+                 u32 split_k_items (the KIND of plan: > 0 = single-image plan lowered with that work-item target, 0 = batch plan),
+                 u32 flags (0), u64 center_floats, params_floats (per image), dev_bytes, host_bytes
     i64          buf_floats[n_bufs]
     romp_op      ops[n_ops]            pointer fields: offset + 1 into the device blob; bit 63 set: into the host blob; 0: null
     PlanInit     inits[n_inits]        {i32 buf, i32 0, u64 floats, u64 device-blob offset}: per-image content of an arena buffer
@@ -27,7 +28,8 @@ from .lib import RompOp
 from .plan import coord_channels, encode_h2
 
 MAGIC = b'ROMPPLAN'
-HEADER = struct.Struct('<8s8I4Q')
+VERSION = 2
+HEADER = struct.Struct('<8s10I4Q')
 INIT = struct.Struct('<iiQQ')
 PTR_FIELDS = ('weight', 'scale', 'shift', 'weight_aux', 'weight_h2', 'scale_h2')
 HOST_BIT = 1 << 63
@@ -52,7 +54,9 @@ def _blobs(program):
 
 def save_plan(net_or_program, path, input_size=512, out_floats=None, tuned=None):
     """Write the plan file.  `net_or_program`: a RompNet (its program, output shapes and the variant tables it has measured)
-    or a bare plan.Program (then pass `out_floats` = per-image floats of the two outputs)."""
+    or a bare plan.Program (then pass `out_floats` = per-image floats of the two outputs).  The plan kind (`split_k_items` of
+    the lowering: single-image or batch plan) goes into the header -- it is a property of how the program was lowered, not
+    something the op list shows."""
     net = None if hasattr(net_or_program, 'ops') else net_or_program
     P = net.program if net is not None else net_or_program
     ops = P.op_array()
@@ -88,8 +92,8 @@ def save_plan(net_or_program, path, input_size=512, out_floats=None, tuned=None)
         dev.extend(raw)
     n_variants = L.load().romp_conv_num_variants()
     with open(path, 'wb') as f:
-        f.write(HEADER.pack(MAGIC, 1, L.ABI_VERSION, n_ops, len(P.buf_floats), len(inits), len(tuned), input_size, C.sizeof(RompOp),
-                            out_floats[0], out_floats[1], len(dev), len(host)))
+        f.write(HEADER.pack(MAGIC, VERSION, L.ABI_VERSION, n_ops, len(P.buf_floats), len(inits), len(tuned), input_size, C.sizeof(RompOp),
+                            int(getattr(P, 'split_k_items', 0) or 0), 0, out_floats[0], out_floats[1], len(dev), len(host)))
         f.write(np.asarray(P.buf_floats, dtype='<i8').tobytes())
         f.write(bytes(packed))
         for buf, floats, off in inits:
@@ -106,9 +110,11 @@ def read_plan(path):
     """Parse a plan file on the host (tests, inspection): dict with the header fields, `buf_floats`, `ops` (RompOp array with
     the ENCODED pointer fields), `inits`, `tuned`, `dev`, `host` (bytes)."""
     raw = open(path, 'rb').read()
-    magic, version, abi, n_ops, n_bufs, n_inits, n_tuned, input_size, op_bytes, cf, pf, dev_bytes, host_bytes = HEADER.unpack_from(raw, 0)
-    if magic != MAGIC or version != 1 or op_bytes != C.sizeof(RompOp):
-        raise L.RompHipError('%s is not a version-1 plan file of this ABI' % path)
+    if len(raw) < HEADER.size:
+        raise L.RompHipError('%s is truncated' % path)
+    magic, version, abi, n_ops, n_bufs, n_inits, n_tuned, input_size, op_bytes, split_k_items, _flags, cf, pf, dev_bytes, host_bytes = HEADER.unpack_from(raw, 0)
+    if magic != MAGIC or version != VERSION or op_bytes != C.sizeof(RompOp):
+        raise L.RompHipError('%s is not a version-%d plan file of this ABI' % (path, VERSION))
     at = HEADER.size
     buf_floats = np.frombuffer(raw, '<i8', n_bufs, at).tolist(); at += 8 * n_bufs
     ops = (RompOp * n_ops).from_buffer_copy(raw, at); at += n_ops * op_bytes
@@ -121,7 +127,7 @@ def read_plan(path):
     host = raw[at:at + host_bytes]; at += host_bytes
     if at != len(raw):
         raise L.RompHipError('%s: %d trailing bytes' % (path, len(raw) - at))
-    return dict(abi=abi, input_size=input_size, center_floats=cf, params_floats=pf, buf_floats=buf_floats, ops=ops,
+    return dict(abi=abi, input_size=input_size, split_k_items=split_k_items, center_floats=cf, params_floats=pf, buf_floats=buf_floats, ops=ops,
                 inits=[(b, fl, off) for b, _, fl, off in inits], tuned=tuned, dev=dev, host=host)
 
 

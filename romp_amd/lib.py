@@ -94,6 +94,7 @@ def load():
         'romp_sim3dr_rasterize': (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
         'romp_net_load': (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, i32]),
         'romp_net_plan_info': (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+        'romp_net_plan_kind': (C.c_int, [vp, C.POINTER(C.c_int32)]),
         'romp_net_set_split': (C.c_int, [vp, i32, i32, C.c_int64, C.c_int64, C.c_int64]),
         'romp_net_set_tuned': (C.c_int, [vp, i32, C.POINTER(C.c_int32), i32]),
         'romp_bev_workspace_ints': (C.c_int, [i32, i32]),
@@ -123,7 +124,7 @@ def load():
 EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_forward', 'romp_net_read_buffer',
            'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_set_streams', 'romp_net_profile', 'romp_net_range_scan', 'romp_net_saturated', 'romp_net_set_sat_check', 'romp_net_destroy',
            'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_trace_read', 'romp_conv_describe',
-           'romp_net_load', 'romp_net_plan_info', 'romp_net_autotune', 'romp_net_tuned_variant', 'romp_net_set_tuned', 'romp_net_set_split', 'romp_project_verts', 'romp_estimate_translation', 'romp_cam_to_trans', 'romp_bev_project_verts', 'romp_oneeuro_state_floats', 'romp_oneeuro_smooth', 'romp_sim3dr_normals', 'romp_sim3dr_light', 'romp_sim3dr_rasterize', 'romp_bev_workspace_ints', 'romp_bev_parse', 'romp_bev_regress',
+           'romp_net_load', 'romp_net_plan_info', 'romp_net_plan_kind', 'romp_net_autotune', 'romp_net_tuned_variant', 'romp_net_set_tuned', 'romp_net_set_split', 'romp_project_verts', 'romp_estimate_translation', 'romp_cam_to_trans', 'romp_bev_project_verts', 'romp_oneeuro_state_floats', 'romp_oneeuro_smooth', 'romp_sim3dr_normals', 'romp_sim3dr_light', 'romp_sim3dr_rasterize', 'romp_bev_workspace_ints', 'romp_bev_parse', 'romp_bev_regress',
            'romp_net_buffer_ptr', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
            'romp_project', 'romp_preprocess', 'romp_preprocess_batch', 'romp_bev_postprocess']
 

@@ -178,17 +178,21 @@ class RompNet:
         self._plan_path = path
         ops = plan['ops']
         self.bf16x3 = any(o.weight_h2 or o.weight_aux for o in ops)
-        self.split, self.split_k, self.input_size = 1, int(any(o.kind == L.OP_KSUM for o in ops)), plan['input_size']
+        self.split, self.split_k, self.input_size = 1, plan['split_k_items'], plan['input_size']     # (the plan KIND is in the header)
         buf_fmt = {}
         for o in ops:
             if o.out_buf >= 0:
                 buf_fmt[o.out_buf] = o.out_fmt
         self.program = SimpleNamespace(ops=list(ops), names=['op%d' % i for i in range(len(ops))], buf_floats=plan['buf_floats'],
-                                       buf_fmt=buf_fmt, flops=[0.0] * len(ops), bytes=[0.0] * len(ops), coord_off=None)
+                                       buf_fmt=buf_fmt, flops=[0.0] * len(ops), bytes=[0.0] * len(ops), coord_off=None,
+                                       split_k_items=plan['split_k_items'])
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self.lib.romp_net_load(C.byref(h), str(path).encode(), self.max_batch))
         self._h = h
+        kind = C.c_int32(-1)
+        L.check(self.lib.romp_net_plan_kind(h, C.byref(kind)))
+        assert kind.value == self.split_k, (kind.value, self.split_k)     # the C reader and read_plan parse one header
         n_variants = self.lib.romp_conv_num_variants()
         self._tuned = {B for B, (nv, _) in plan['tuned'].items() if nv == n_variants and B <= self.max_batch}
         ms = self.input_size // 8

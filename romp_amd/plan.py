@@ -256,6 +256,14 @@ def assign_formats(P):
                         # an f16x2 kernel would split this float32 tensor in registers with the same 2^ACT_SHIFT: not this op
                         P.ops[i].weight_h2, P.ops[i].scale_h2 = 0, 0
                         P.range_fallback.append((i, P.names[i] if i < len(P.names) else 'op%d' % i, m))
+                        o = P.ops[i]
+                        if getattr(P, 'split_k_items', 0) and o.groups == 1 and o.Cin % 64 == 0 and o.Cout % 32 == 0 and o.ksize in (1, 3):
+                            # split_k_groups left this layer whole for conv_h2k, which only runs on H2 tensors: on the f32 kernels it
+                            # is a handful of work items with a serial loop over all input channels (slow at B = 1, still correct)
+                            import warnings
+                            warnings.warn('single-image plan: %s fell back to the float32 kernels (max|x| %.3g outside the fp16 pieces) and '
+                                          'runs WITHOUT its input-channel split -- expect a slower frame; calibrate on representative '
+                                          'frames or lower with ROMP_KSPLIT_WG=0' % (P.names[i] if i < len(P.names) else 'op%d' % i, m))
         fmt = FMT_H2 if (g['ok'] and any(r == 'out' for _, r in g['uses'])) else FMT_F32
         P.buf_fmt[g['buf']] = fmt
         for i, role in g['uses']:
@@ -324,6 +332,8 @@ def fuse_bottleneck_seams(P):
 
 
 FUP_TILE = {32: (8, 64), 64: (8, 32), 128: (4, 32)}          # csrc/conv_fup.hip: output tile (rows, columns) by channel count
+FUP_MAX_DIRECT = {32: 1, 64: 2, 128: 3}                      # FupCfg::MAXD: direct terms per output channel count
+FUP_KERNELS = {(32, 1), (32, 2), (32, 3), (64, 1), (64, 2), (128, 1)}   # (Cout, up-terms) launch_fuseup instantiates
 
 
 def fuse_up_sums(P):
@@ -349,8 +359,11 @@ def fuse_up_sums(P):
         shifts = [F.term_shift[k] for k in range(F.n_terms)]
         n_dir = sum(1 for s in shifts if s == 0)
         ups = shifts[n_dir:]
-        if not (1 <= n_dir <= 3 and ups and shifts[:n_dir] == [0] * n_dir and ups == list(range(1, len(ups) + 1)) and
-                F.H % th == 0 and F.W % tw == 0 and all(F.term_fmt[k] == FMT_H2 for k in range(F.n_terms)) and (th >> len(ups)) >= 1):
+        # exactly the kernels csrc/conv_fup.hip instantiates (launch_fuseup: (Cout, up-terms); FupCfg::MAXD direct terms) --
+        # any other branch layout stays on FUSESUM + separate 1x1 convs
+        if not (1 <= n_dir <= FUP_MAX_DIRECT[F.Cout] and (F.Cout, len(ups)) in FUP_KERNELS and shifts[:n_dir] == [0] * n_dir and
+                ups == list(range(1, len(ups) + 1)) and F.H % th == 0 and F.W % tw == 0 and
+                all(F.term_fmt[k] == FMT_H2 for k in range(F.n_terms)) and (th >> len(ups)) >= 1):
             continue
         prods = []
         for u, k in enumerate(range(n_dir, F.n_terms)):

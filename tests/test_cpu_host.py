@@ -420,6 +420,7 @@ def test_plan_file_roundtrip_on_host(tmp_path):
     plan = export.read_plan(path)
     ops = P.op_array()
     assert plan['abi'] == L.ABI_VERSION and plan['input_size'] == 512 and plan['buf_floats'] == list(P.buf_floats)
+    assert plan['split_k_items'] == 128                     # the plan KIND is a header field (a batch plan writes 0, below)
     assert (plan['center_floats'], plan['params_floats']) == (64 * 64, 64 * 64 * 145) and list(plan['tuned']) == [1]
     by_ptr = {c.data_ptr(): c for c in P.consts if hasattr(c, 'data_ptr')}
     checked = 0
@@ -456,6 +457,7 @@ def test_export_cli_bev_host_tables(tmp_path):
     export.main(['--model_path', ckpt, '-o', plan_path, '--bev'])
     plan = export.read_plan(plan_path)
     assert (plan['center_floats'], plan['params_floats']) == (64 * 128 * 128, 3 * 64 * 128 * 128) and plan['inits'] == []
+    assert plan['split_k_items'] == 0                       # --max_batch 32 (the default): a batch plan
     host_ops = [o for o in plan['ops'] if o.kind in (OP_BEV_MAPS, OP_CONV3D)]
     assert len(host_ops) == 5 and all(o.weight & export.HOST_BIT for o in host_ops)
     maps = [o for o in host_ops if o.kind == OP_BEV_MAPS][0]

@@ -697,6 +697,9 @@ def test_plan_file_c_abi_only(dev, tmp_path):
             size, cf, pf, n_ops = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int32()
             L.check(lib.romp_net_plan_info(h, C.byref(size), C.byref(cf), C.byref(pf), C.byref(n_ops)))
             assert (size.value, cf.value, pf.value, n_ops.value) == (512, 64 * 64, 64 * 64 * 145, len(net.program.ops))
+            kind = C.c_int32(-1)
+            L.check(lib.romp_net_plan_kind(h, C.byref(kind)))                # the plan KIND travels in the header (single-image: 128 items)
+            assert kind.value == net.split_k == (128 if max_batch == 1 else 0)
             assert [lib.romp_net_tuned_variant(h, B, i) for i in range(n_ops.value)] == net.tuned_variants(B)
             c1, p1 = torch.empty_like(c0), torch.empty_like(p0)
             L.check(lib.romp_net_forward(h, L.ptr(img), B, L.ptr(c1), L.ptr(p1), L.stream_ptr(dev)))
@@ -706,7 +709,7 @@ def test_plan_file_c_abi_only(dev, tmp_path):
             lib.romp_net_destroy(h)
         net2 = RompNet.from_plan(path, dev, max_batch=max_batch)
         c2, p2 = net2.forward_nhwc(img)
-        assert torch.equal(c2, c0) and torch.equal(p2, p0) and net2.split_k == (1 if max_batch == 1 else 0)
+        assert torch.equal(c2, c0) and torch.equal(p2, p0) and net2.split_k == net.split_k == (128 if max_batch == 1 else 0)
     # the drop-in API from the plan file (the reference's --onnx branch, main.py:86-89): same result dict as from the state_dict
     import romp_amd
     rs = np.random.RandomState(0)
