@@ -187,16 +187,22 @@ def usable_cores():
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline / parity
-def cpu_baseline(sd, smpl_model, thresh, seconds):
+def cpu_baseline(sd, smpl_model, thresh, seconds, backbone='hrnet32'):
     """The reference's CPU path on a bounded sample of the same workload, on this box's host cores: the REFERENCE ITSELF
     (ROMPv1 + parsing_outputs + SMPL of simple_romp/romp, run from oracle/_ref/romp/*.pyc, kind "reference") when
-    oracle/Makefile staged it, else the oracle restatement (kind "port")."""
+    oracle/Makefile staged it, else the oracle restatement (kind "port").  --backbone resnet50: the reference's ResNet-50 lives
+    in its training tree (romp/lib/models/resnet_50.py), whose package cannot be staged sourceless the same way -- the restated
+    oracle (oracle/resnet_oracle.py, pinned to the reference module by tests/golden/resnet50_b1.npz) is timed: kind "port"."""
     from oracle import romp_oracle as O, ref_cpu
     from romp_amd import synthetic as S
     torch.set_num_threads(usable_cores())
     Bc = 4
     img = S.make_images(Bc, seed=1)
-    kind = 'reference' if ref_cpu.available() else 'port'
+    kind = 'reference' if (ref_cpu.available() and backbone == 'hrnet32') else 'port'
+    net_oracle = O.romp_net_forward
+    if backbone == 'resnet50':
+        from oracle import resnet_oracle as RO
+        net_oracle = RO.resnet_romp_forward
     if kind == 'reference':
         pipe = ref_cpu.ReferencePipeline(sd, smpl_model, thresh)
 
@@ -204,7 +210,7 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
             pipe(img)
     else:
         def step():
-            cm, pm = O.romp_net_forward(sd, img)
+            cm, pm = net_oracle(sd, img)
             r = O.parsing_outputs(cm.numpy(), pm.numpy(), thresh)
             if r is not None:
                 O.smpl_forward(smpl_model, r['smpl_betas'], r['smpl_thetas'])
@@ -223,42 +229,55 @@ def cpu_baseline(sd, smpl_model, thresh, seconds):
             '(smpl.py:62-108), PyTorch-CPU float32, byte-compiled from /root/reference into oracle/_ref/romp (its onnxruntime '
             'session, main.py:86-89, needs a module that is not installed: this is the --onnx=False path, main.py:74-77)'
             if kind == 'reference' else
+            'the oracle restatement of the reference ResNet-50 ROMP (romp/lib/models/resnet_50.py:19-120 + the ROMPv1 head, parse, SMPL) on '
+            'torch-CPU float32: oracle/resnet_oracle.py' if backbone == 'resnet50' else
             'the oracle restatement of the reference on torch-CPU float32 (oracle/_ref/romp is not staged on this box)')
     return dict(value=round(Bc * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind=kind,
                 sample='%d iterations of batch %d (net+parse+SMPL) of the same synthetic workload: %s' % (n, Bc, what))
 
 
-def parity_report(model, images, sd, smpl_model, thresh, pick=(0, 17)):
-    """Images `pick` of the timed batch: HIP maps / detections / meshes against the oracle pipeline (BASELINE metric:
-    'mesh max-abs-err vs ref')."""
+def parity_report(model, images, sd, smpl_model, thresh, mesh_pick=(0, 7, 17, 31), net_oracle=None):
+    """The WHOLE first call of the timed job (all `images`, 32 by default): HIP maps and detections of every image against the
+    oracle pipeline, and the meshes of every person of the images `mesh_pick` (BASELINE metric: 'mesh max-abs-err vs ref').
+    `net_oracle(sd, images_nhwc) -> (center_maps, params_maps)`: the oracle network (default: HRNet-32, oracle/romp_oracle.py;
+    --backbone resnet50 passes oracle/resnet_oracle.py's)."""
     import numpy as np
     from oracle import romp_oracle as O
     torch.set_num_threads(usable_cores())
-    pick = [p for p in pick if p < images.shape[0]]
+    net_oracle = net_oracle or O.romp_net_forward
+    n = images.shape[0]
     cm, pm = model.model(images)
     out, bids = model.forward_batch(images)
     torch.cuda.synchronize()
-    cm_o, pm_o = O.romp_net_forward(sd, images[pick].cpu())
-    rep = {'images_compared': pick,
-           'maps_max_abs_vs_oracle': float(max((cm[pick].cpu() - cm_o).abs().max(), (pm[pick].cpu() - pm_o).abs().max()))}
+    cms, pms = [], []
+    for c0 in range(0, n, 8):                                 # (8 images at a time: bounds the host memory of the float32 oracle)
+        c_, p_ = net_oracle(sd, images[c0:c0 + 8].cpu())
+        cms.append(c_); pms.append(p_)
+    cm_o, pm_o = torch.cat(cms), torch.cat(pms)
+    per_image = torch.maximum((cm.cpu() - cm_o).abs().flatten(1).max(1).values, (pm.cpu() - pm_o).abs().flatten(1).max(1).values)
+    rep = {'images_compared': list(range(n)), 'maps_max_abs_vs_oracle': float(per_image.max()),
+           'maps_max_abs_worst_image': int(per_image.argmax())}
     ref = O.parsing_outputs(cm_o.numpy(), pm_o.numpy(), thresh)
     if out is None or ref is None:
-        rep['detections_equal'] = (out is None or not any(int(b) in pick for b in bids.tolist())) and ref is None
+        rep['detections_equal'] = out is None and ref is None
         return rep
     b = bids.cpu().numpy()
-    rows = np.concatenate([np.nonzero(b == p)[0] for p in pick])
-    same = (len(rows) == len(ref['batch_ids']) and np.array_equal(np.searchsorted(pick, b[rows]), ref['batch_ids']) and
-            np.array_equal(out['center_preds'].cpu().numpy()[rows], ref['center_preds']))
+    same = (len(b) == len(ref['batch_ids']) and np.array_equal(b, ref['batch_ids']) and
+            np.array_equal(out['center_preds'].cpu().numpy(), ref['center_preds']))
     rep['detections_equal'] = bool(same)
-    rep['persons_compared'] = int(len(rows))
+    rep['persons_compared'] = int(len(b))
+    rep['thetas_max_abs_vs_oracle'] = float(np.abs(out['smpl_thetas'].cpu().numpy() - ref['smpl_thetas']).max()) if same else None
+    mesh_pick = [i for i in mesh_pick if i < n]
+    rows = np.nonzero(np.isin(b, mesh_pick))[0]
+    rep['mesh_images_compared'] = mesh_pick
     if same and len(rows):
         th, be = out['smpl_thetas'].cpu().numpy()[rows], out['smpl_betas'].cpu().numpy()[rows]
         v = out['verts'].cpu().numpy()[rows]
         vo, _, _ = O.smpl_forward(smpl_model, be, th)                                   # identical theta / beta (the 1e-4 gate)
-        vr, _, _ = O.smpl_forward(smpl_model, ref['smpl_betas'], ref['smpl_thetas'])    # the oracle's own theta / beta
+        vr, _, _ = O.smpl_forward(smpl_model, ref['smpl_betas'][rows], ref['smpl_thetas'][rows])    # the oracle's own theta / beta
+        rep['mesh_persons_compared'] = int(len(rows))
         rep['mesh_max_abs_vs_oracle'] = float(np.abs(v - vo).max())
         rep['mesh_max_abs_end_to_end'] = float(np.abs(v - vr).max())
-        rep['thetas_max_abs_vs_oracle'] = float(np.abs(th - ref['smpl_thetas']).max())
     return rep
 
 
@@ -658,7 +677,6 @@ def main():
     settings.conv_math, settings.backbone = args.conv_math, args.backbone
     if args.backbone == 'resnet50':
         sd = S.make_resnet_state_dict(0, center_bias=2.0)
-        args.no_cpu_baseline = args.no_parity = True          # those legs run the HRNet-32 oracle
     else:
         sd = S.make_romp_state_dict(0)
     smpl_model = S.make_smpl_model(0)
@@ -711,7 +729,11 @@ def main():
             result['kernel_classes'] = classes
         if not args.no_parity:
             with torch.cuda.stream(stream):
-                result['config'].update(parity_report(model, first, sd, smpl_model, args.center_thresh))
+                net_oracle = None
+                if args.backbone == 'resnet50':
+                    from oracle import resnet_oracle as RO
+                    net_oracle = RO.resnet_romp_forward
+                result['config'].update(parity_report(model, first, sd, smpl_model, args.center_thresh, net_oracle=net_oracle))
         if world == 1 and not args.no_end_to_end:
             result['end_to_end'] = end_to_end(model, lib, L, dev, B, max(8, min(32, n_local // B)), stream)
         if world == 1 and args.conv_math != 'f32' and args.backbone == 'hrnet32' and not args.no_f32_companion:
@@ -741,7 +763,7 @@ def main():
         if world == 1 and args.backbone == 'hrnet32' and not args.no_latency:
             result['single_image_latency'] = single_image_latency(sd, smpl_model, args, dev, stream)
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(sd, smpl_model, args.center_thresh, args.cpu_seconds)
+            result['cpu_baseline'] = cpu_baseline(sd, smpl_model, args.center_thresh, args.cpu_seconds, args.backbone)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

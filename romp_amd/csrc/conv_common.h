@@ -30,15 +30,12 @@ struct ConvParams {
     int tiles_x, tiles_y, tiles_total;
     int nslices, ns_total;    // channel slices per group; slices*groups
     int n_queues, per_queue;  // 8 (XCD-aware) or 1
-    int tile_contig;          // queue q owns tiles [q * tiles_total / 8, ...) instead of every 8th tile (decode_item)
     int vec_io;               // epilogue may use float4 loads/stores
     int w_gs;                 // floats per group in the packed weight
     int pad_h, pad_w;         // rows / columns of zero padding before the first tap
     int out_rs, out_bs;       // output row stride / image stride in floats (dense: Wo*out_cs, Ho*Wo*out_cs)
     unsigned long long* trace;   // nullptr, or TRACE_SLOTS words per wave: (s_memtime << 8 | event code) stamps (env ROMP_CONV_TRACE=1;
                                  // split-precision kernels only; read back with romp_conv_trace_read, scripts/conv_trace.py)
-    int* cu_slots;            // per-CU arrival counters (experiment: phase skew between the workgroups sharing a CU), or nullptr
-    int skew;                 // env ROMP_CONV_SKEW: cycles of start delay per arrival slot on a CU (0 = off)
     float* out2; int out2_cs, out2_co;   // (conv_h2x.hip) the second output tensor
     unsigned in_bytes;        // (fused block kernel) bytes of the input tensor from in + in_co on: num_records of its raw buffer
     int relu_from;            // relu != 0: ReLU on output channels >= relu_from only (romp_op.relu_from; a multiple of 32)
@@ -148,23 +145,6 @@ struct ConvCfg {                                     // NWV: waves per workgroup
 
 struct Item { int b, ty, tx, n0, g; };
 
-// Experiment (ROMP_CONV_SKEW): the workgroups that share a CU start in lockstep, so all of them are in their load phase, then all
-// in their MFMA phase, ...  Delaying the k-th arrival on a CU by k * skew cycles staggers the phases.
-__device__ __forceinline__ void cu_phase_skew(const ConvParams& p) {
-    if (p.skew <= 0 || !p.cu_slots) return;
-    __shared__ int s_slot;
-    if (threadIdx.x == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, bits 0..31
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15; // HW_REG_XCC_ID
-        const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
-        s_slot = atomicAdd(p.cu_slots + (((xcc * 8 + se) * 2 + sh) * 16 + cu), 1) & 3;
-    }
-    __syncthreads();
-    const long long t0 = clock64();
-    const long long wait = (long long)s_slot * p.skew;
-    while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-}
-
 constexpr int TRACE_SLOTS = 64, TRACE_WAVES = 4096;
 // one stamp per wave (lane 0): word 0 of the wave's slot block counts the stamps, words 1.. hold them.  The kernel defines
 // `int tr_n = 0` and `constexpr int tr_wpw` = its waves per workgroup.
@@ -183,11 +163,11 @@ constexpr int TRACE_SLOTS = 64, TRACE_WAVES = 4096;
 
 __device__ __forceinline__ Item decode_item(const ConvParams& p, int q, int j, int NW) {
     const int s = j % p.ns_total, tl = j / p.ns_total;
-    // Which tiles a queue (= an XCD, blockIdx % 8) owns.  tile_contig: a contiguous run of tiles_total / 8 tiles, i.e. whole
-    // images / image halves: the workgroups of one XCD then work on spatially adjacent tiles at the same time and the 3x3
-    // halo re-reads hit that XCD's L2 (round 3: measured FETCH_SIZE of the 16x16-tile 3x3 kernels was 1.27-1.31x algorithmic =
-    // exactly their haloed / plain pixel ratio -- every halo row came over the fabric again).  Else: interleaved (round 1-2).
-    int t = p.tile_contig ? q * (p.tiles_total / p.n_queues) + tl : tl * p.n_queues + q;
+    // A queue (= an XCD, blockIdx % 8) owns a contiguous run of tiles_total / 8 tiles, i.e. whole images / image halves: the
+    // workgroups of one XCD then work on spatially adjacent tiles at the same time and the 3x3 halo re-reads hit that XCD's L2
+    // (round 3: with every 8th tile per queue the measured FETCH_SIZE of the 16x16-tile 3x3 kernels was 1.27-1.31x algorithmic =
+    // exactly their haloed / plain pixel ratio -- every halo row came over the fabric again).
+    int t = q * (p.tiles_total / p.n_queues) + tl;
     Item it;
     it.g = s / p.nslices;
     it.n0 = (s % p.nslices) * NW;

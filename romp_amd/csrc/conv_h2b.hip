@@ -20,7 +20,7 @@
 // micro-steps of a few instructions, one behind each MFMA, pinned there (sched_barrier); table reads are issued an LDS round trip
 // ahead of their use.  History and measurements: profiles/r03_fused_blocks_notes.md.  Batch plans run the 32-channel blocks on
 // conv_h2c.hip's row-pipelined kernel instead (launch_bblock32 hands over when the ops carry per-wave weight packs); this kernel
-// serves single-image plans and ROMP_BBLOCK32=v1.
+// serves single-image plans.
 #include "conv_split.h"
 #include "conv_fuse.h"
 #include <string.h>
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
 // `op` is the block's SECOND conv (its residual is the block input x, its output y); `op1` the first (weights / scale / shift).
 int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
     {   // two implementations: this file's (v1: 16x16 tiles, one wave per SIMD) and conv_h2c.hip's row-pipelined one (two waves per SIMD)
-        // The plan decides (plan.fuse_basic_blocks; env ROMP_BBLOCK32=v1 there keeps this file's kernel everywhere): the row-pipelined
+        // The plan decides (plan.fuse_basic_blocks): the row-pipelined
         // kernel needs the per-wave weight packs, announced by ROMP_OPF_WAVE16 -- weight_aux alone may just as well be the bf16x3 pack
         // of conv_math='all' (a single-image 'all' plan ran the row kernel on bf16x3 bytes).
         if ((op1.flags & op.flags & ROMP_OPF_WAVE16) && op.H % 8 == 0) return launch_bblock32r(op1, op, x, y, B, queue, st);
@@ -557,7 +557,6 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     p.nslices = p.ns_total = 1;
     p.n_queues = (p.tiles_total % 8 == 0) ? 8 : 1;
     p.per_queue = p.tiles_total / p.n_queues;
-    p.tile_contig = 1;
     p.vec_io = 1;
     p.pad_h = p.pad_w = 1;
     p.out_rs = op.out_rstride > 0 ? op.out_rstride : p.Wo * op.out_cstride;

@@ -544,7 +544,6 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     p.nslices = p.ns_total = 1;
     p.n_queues = (p.tiles_total % 8 == 0) ? 8 : 1;
     p.per_queue = p.tiles_total / p.n_queues;
-    p.tile_contig = 1;
     p.vec_io = 1;
     p.pad_h = p.pad_w = 1;
     p.out_rs = op.out_rstride > 0 ? op.out_rstride : p.Wo * op.out_cstride;
@@ -562,7 +561,7 @@ int launch_bblock64(const romp_op& op1, const romp_op& op, const float* x, float
     return launch_bblockr<64>(op1, op, x, y, B, queue, st);
 }
 // the 32-channel block in the same row-pipelined form, two workgroups per CU (conv_h2b.hip's launch_bblock32 hands over to it when
-// the ops carry per-wave weight packs and ROMP_BBLOCK32 does not say v1)
+// the ops carry per-wave weight packs)
 int launch_bblock32r(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
     return launch_bblockr<32>(op1, op, x, y, B, queue, st);
 }

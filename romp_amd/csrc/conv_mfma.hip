@@ -54,8 +54,6 @@ static void collect_variants() {
 static bool g_attr_done = false;
 static int g_num_cu = 256;
 static int* g_queue_scratch = nullptr;      // for romp_conv_forward callers without an arena
-static int* g_cu_slots = nullptr;           // ROMP_CONV_SKEW experiment: per-CU arrival counters
-static int g_skew = 0;
 static float* g_zero = nullptr;             // 256 bytes of zeros (out-of-image lanes of LDS-DMA pixel fetches)
 // Per HOST THREAD: the executor names its net's counter / cap right before it enqueues on that thread, so two nets driven from two
 // threads (RompNet.twin, ROMP_PIPE_NETS=2, a host with one net per thread) never see each other's values.
@@ -85,8 +83,6 @@ static int ensure_attrs() {
     }
     ROMP_HIP_CHECK(hipMalloc((void**)&g_queue_scratch, QUEUE_INTS * sizeof(int)));
     ROMP_HIP_CHECK(hipMalloc((void**)&g_zero, 256));
-    { const char* e = getenv("ROMP_CONV_SKEW"); g_skew = e ? atoi(e) : 0;
-      if (g_skew > 0) { ROMP_HIP_CHECK(hipMalloc((void**)&g_cu_slots, 8 * 8 * 2 * 16 * sizeof(int))); ROMP_HIP_CHECK(hipMemset(g_cu_slots, 0, 8 * 8 * 2 * 16 * sizeof(int))); } }
     ROMP_HIP_CHECK(hipMemset(g_zero, 0, 256));
     { const char* e = getenv("ROMP_CONV_TRACE");
       if (e && atoi(e)) ROMP_HIP_CHECK(hipMalloc((void**)&g_trace, (size_t)TRACE_WAVES * TRACE_SLOTS * sizeof(unsigned long long))); }
@@ -149,15 +145,7 @@ static void out_dims(const romp_op& op, int* Ho, int* Wo) {
 int conv_num_variants() { collect_variants(); return kNumVariants; }
 
 bool conv_variant_valid(const romp_op& op, int variant);
-static int g_no_h2r = -1;                   // env ROMP_CONV_NO_H2R=1: keep the register-weight kernels (conv_h2r.hip) out of the autotuner (A/B runs)
-bool conv_variant_tunable(const romp_op& op, int variant) {
-    if (g_no_h2r < 0) { const char* e = getenv("ROMP_CONV_NO_H2R"); g_no_h2r = (e && atoi(e)) ? 1 : 0; }
-    if (kVariants[variant].math == 8 && g_no_h2r) return false;
-    { static int no_h2s = -1;                                   // env ROMP_CONV_NO_H2S=1: the stride-2 convs on the round-3 kernels (A/B runs)
-      if (no_h2s < 0) { const char* e = getenv("ROMP_CONV_NO_H2S"); no_h2s = (e && atoi(e)) ? 1 : 0; }
-      if (kVariants[variant].math == 9 && no_h2s) return false; }
-    return conv_variant_valid(op, variant);
-}
+bool conv_variant_tunable(const romp_op& op, int variant) { return conv_variant_valid(op, variant); }
 
 bool conv_variant_valid(const romp_op& op, int variant) {
     collect_variants();
@@ -180,7 +168,6 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.wh = reinterpret_cast<const uint4*>(op.weight_h2);
     p.scale_h = op.scale_h2;
     p.zero = g_zero;
-    p.cu_slots = g_cu_slots; p.skew = g_skew;
     p.act_scale = ldexpf(1.f, op.act_shift);
     p.inv_act_scale = ldexpf(1.f, -op.act_shift);
     p.in_h2 = op.in_fmt == ROMP_FMT_H2; p.out_h2 = op.out_fmt == ROMP_FMT_H2; p.res_h2 = res && op.res_fmt == ROMP_FMT_H2;
@@ -233,9 +220,6 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
     p.nslices = op.cout_pad / (v.nt * 32);
     p.ns_total = p.nslices * op.groups;
     p.n_queues = (p.tiles_total % 8 == 0) ? 8 : 1;
-    { static int contig = -1;
-      if (contig < 0) { const char* e = getenv("ROMP_TILE_ORDER"); contig = (e && atoi(e) == 0) ? 0 : 1; }   // ROMP_TILE_ORDER=0: interleaved (A/B runs)
-      p.tile_contig = contig; }
     p.per_queue = (p.tiles_total / p.n_queues) * p.ns_total;
     if (queue == nullptr) {
         queue = g_queue_scratch;

@@ -318,7 +318,6 @@ __device__ __forceinline__ void conv_split_body(const ConvParams& p) {
 
     int tr_n = 0;
     constexpr int tr_wpw = 4;
-    cu_phase_skew(p);
     ROMP_TRACE(1);                                     // kernel entry
     Item cur = decode_item(p, q, j_cur, C::NW);
     issue_loads(cur, 0);
@@ -511,7 +510,6 @@ __device__ __forceinline__ void conv_splitd_body(const ConvParams& p) {
 
     int tr_n = 0;
     constexpr int tr_wpw = 4;
-    cu_phase_skew(p);
     ROMP_TRACE(1);
     Item cur = decode_item(p, q, j_cur, C::NW);
     issue_B(cur, 0, 0, 0);

@@ -16,8 +16,6 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdint.h>
-#include <signal.h>
-#include <execinfo.h>
 #include <unistd.h>
 
 namespace romp {
@@ -424,32 +422,9 @@ extern "C" {
 int romp_abi_version(void) { return ROMP_ABI_VERSION; }
 const char* romp_last_error(void) { return romp::g_err; }
 
-// Debugging aid (env ROMP_SEGV_BACKTRACE=1): native frames of a SIGSEGV on an alternate stack -- a crash inside the HIP runtime (graph
-// instantiation recursing off the stack, say) otherwise shows Python frames only.
-static void segv_backtrace(int sig, siginfo_t* si, void*) {
-    void* frames[64];
-    char line[128];
-    int n = snprintf(line, sizeof line, "== signal %d at address %p; innermost frames:\n", sig, si ? si->si_addr : nullptr);
-    if (write(2, line, n) < 0) _exit(139);
-    backtrace_symbols_fd(frames, backtrace(frames, 64), 2);
-    _exit(139);
-}
-
 int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const int64_t* buf_floats, int n_bufs,
                     int max_batch) {
     ROMP_REQUIRE(out && ops_host && n_ops > 0 && n_bufs >= 0 && max_batch > 0, "romp_net_create: bad arguments");
-    {
-        static bool armed = false;
-        if (!armed && getenv("ROMP_SEGV_BACKTRACE")) {
-            armed = true;
-            static char alt[1 << 16];
-            stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof alt; ss.ss_flags = 0;
-            sigaltstack(&ss, nullptr);
-            struct sigaction sa; memset(&sa, 0, sizeof sa);
-            sa.sa_sigaction = segv_backtrace; sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
-            sigaction(SIGSEGV, &sa, nullptr);
-        }
-    }
     {   // One device per process (the design: one process per GPU, torch.distributed over RCCL): the launchers cache their one-time
         // set-up -- raised dynamic-LDS limits, CU count, zero pages, occupancy -- per PROCESS.  A second net on another device would
         // silently run with the first device's, so it is refused here.
@@ -591,8 +566,7 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
     // The stem is the only op that reads the caller's image: launched eagerly in front of the graph, the graph no longer
     // depends on WHERE the input lives (a caller streaming frames from ever new tensors replays one graph).
-    static const bool stem_in_graph = getenv("ROMP_STEM_IN_GRAPH") != nullptr;      // A/B switch for the measurement in DESIGN.md
-    const bool stem_out = !stem_in_graph && !lanes_active(n, B) && n->image_only_in_op0;
+    const bool stem_out = !lanes_active(n, B) && n->image_only_in_op0;
     const float* key_image = stem_out ? nullptr : image;
     if (n->graphs.size() >= 32 && !n->graphs.count(GraphKey{B, key_image, center, params, lanes_active(n, B) ? 0 : -1})) {
         // a caller that hands over new tensors every call must not grow the cache for ever

@@ -301,13 +301,10 @@ class ROMP(nn.Module):
             # its twin (RompNet.twin: own arena and graphs, shared weights), each on its own stream, half a period apart, so that one
             # forward's HBM-bound single-kernel phases (stem, layer1, head: 3.9 of a forward's 10.9 ms, scripts/timeline.py) could run
             # beside the other's matrix-bound HRNet modules.  Measured: 2 964 -> 2 977 images/s (+0.4 %) on one box, 2 847 = 2 847 on
-            # another; with every kernel capped at one workgroup per CU (ROMP_PIPE_WGCAP=1) 2 765: the persistent kernels fill every CU
+            # another; with every kernel capped at one workgroup per CU 2 765: the persistent kernels fill every CU
             # slot, so two forwards time-slice at kernel granularity instead of overlapping.  Not worth a second arena.
             two = os.environ.get('ROMP_PIPE_NETS', '1') == '2' and len(starts) > 1 and self.model.max_batch > 2
             nets = [self.model, self.model.twin()] if two else [self.model, self.model]
-            if two and os.environ.get('ROMP_PIPE_WGCAP'):             # experiment: every kernel leaves half of each CU to the other net's
-                for net in nets:
-                    net.set_split(1, wg_cap=int(os.environ['ROMP_PIPE_WGCAP']))
             streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if two else [torch.cuda.Stream(dev)] * 2
             self._pipe = dict(nets=nets, streams=streams, bufs={}, ev_net=[torch.cuda.Event(), torch.cuda.Event()],
                               ev_free=[torch.cuda.Event(), torch.cuda.Event()])

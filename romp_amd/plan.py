@@ -518,9 +518,8 @@ def fuse_basic_blocks(P):
         if plain and chained and h2 and private and a.act_shift == b.act_shift:
             # the row-pipelined kernels (conv_h2c.hip) read their weights per wave (16 output channels each).  32 channels: batch plans only
             # (two workgroups per CU; a single image's tiles are better off on conv_h2b.hip's kernel: 2.10 vs 2.15 ms at B = 1)
-            # ROMP_BBLOCK32=v1: conv_h2b.hip's kernel everywhere (A/B runs); anything else: the default
-            # ROMP_BBLOCK32=r1: the row-pipelined kernel in single-image plans too (A/B runs)
-            if C_ == 64 or (os.environ.get('ROMP_BBLOCK32', 'r') != 'v1' and not getattr(P, 'split_k_items', 0)) or os.environ.get('ROMP_BBLOCK32') == 'r1':
+            # (round 4 A/B runs, both neutral: conv_h2b's kernel in batch plans, the row-pipelined one at B = 1 -- 1.436 / 1.479 vs 1.458 / 1.461 ms)
+            if C_ == 64 or not getattr(P, 'split_k_items', 0):
                 by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
                 for o in (a, b):
                     t = pack_h2_wave16(by_ptr[o.weight_h2].view(9, C_ // 16, 2, 2, C_, 8))
@@ -667,8 +666,7 @@ class Program:
         if self.split_k_items <= 0 or ksize not in (1, 3) or Wo % 16 or cout % 8:
             return 1
         import os
-        if (self.f16x2 and (stride == 1 or (ksize == 3 and os.environ.get('ROMP_KSPLIT_S2', '1') != '0')) and cin % 64 == 0 and cout % 32 == 0 and
-                os.environ.get('ROMP_KSPLIT_WG', '1') != '0'):
+        if self.f16x2 and (stride == 1 or ksize == 3) and cin % 64 == 0 and cout % 32 == 0 and os.environ.get('ROMP_KSPLIT_WG', '1') != '0':
             # round 4: csrc/conv_h2k.hip splits the input channels across the WAVES of a workgroup and reduces in LDS -- the layer
             # stays one conv op (no float32 partial tensors, no ksum launch); the autotuner picks it wherever the tensors are H2
             return 1

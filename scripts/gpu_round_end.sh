@@ -1,15 +1,19 @@
 #!/bin/bash
-# Everything a round's profiles/ needs, in one gpurun call: the driver's checks (smoke, GPU suite, default bench line twice), the
-# rocprofv3 / PMC passes of the same command, the fused-block phase traces, the B=1 latency breakdown and the secondary bench lines.
+# THE way a round ends: on the FINAL commit, after the last code change -- smoke, the FULL GPU suite exactly as the
+# driver runs it (-x -q; a second pass without -x only if it failed, to see everything that is red), then the default bench line.
+# Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_round_end.sh'
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-bash scripts/gpu_final.sh > gpurun_out/final_run.log 2>&1
-tail -4 gpurun_out/final_run.log
-bash scripts/gpu_profile.sh > gpurun_out/profile_run.log 2>&1
-grep -E "exit|aligned" gpurun_out/profile_run.log | head -12
-for c in 32 64; do
-  (for d in 0 7 8 1 2 4; do echo "== ROMP_CONV_DEBUG=$d"; BB_C=$c BB_FUSED_ONLY=$([ $d = 0 ] && echo 0 || echo 1) ROMP_CONV_DEBUG=$d ROMP_CONV_TRACE=1 timeout 100 python scripts/bblock_bench.py 2>&1 | grep -v amdgpu.ids | head -22; done) > gpurun_out/bblock${c}_trace.txt 2>&1
-done
-timeout 200 python scripts/latency_b1.py 2>&1 | grep -v amdgpu.ids > gpurun_out/latency_b1.txt; cat gpurun_out/latency_b1.txt
-bash scripts/gpu_bench_lines.sh 2>&1 | tail -8
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/round_end_tests.log | tail -6
+if ! grep -q " passed" gpurun_out/round_end_tests.log || grep -q " failed" gpurun_out/round_end_tests.log; then
+    timeout 900 python -m pytest tests -m gpu -q 2>&1 | tee gpurun_out/round_end_tests_all.log | tail -30
+fi
+timeout 600 python bench.py 2>gpurun_out/round_end_bench.err | grep '^{' | tail -1 > gpurun_out/round_end_bench.json
+python - <<'PY'
+import json
+r = json.load(open('gpurun_out/round_end_bench.json'))
+print(r['value'], r['unit'], 'ms/call', r['config'].get('ms_per_call'), 'roofline', r['roofline']['kernel'], r['roofline']['frac'],
+      'cpu', r['cpu_baseline']['value'], 'parity', r['config'].get('maps_max_abs_vs_oracle'), r['config'].get('mesh_max_abs_vs_oracle'), r['config'].get('detections_equal'))
+PY

@@ -497,7 +497,7 @@ def test_hrnet_program_fusions_are_the_documented_ones(monkeypatch):
             if k in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1):
                 assert ks[i - 1] == L.OP_NOP, (i, P.names[i])
         return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), ks.count(L.OP_SEAM1X1), ks.count(L.OP_FUSEUP), ks.count(L.OP_FUSESUM), ks.count(L.OP_NOP)
-    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_BBLOCK32', 'ROMP_FUSEUP', 'ROMP_MERGE_S2'):
+    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_FUSEUP', 'ROMP_MERGE_S2'):
         monkeypatch.delenv(v, raising=False)
     # round 4: 16 of the 23 fuse-layer outputs have up-terms: each runs as FUSEUP and the 18 (merged) 1x1 up-convs become NOPs
     assert kinds() == (32, 32, 3, 16, 7, 67 + 18)
