@@ -98,7 +98,7 @@ __device__ __forceinline__ void h2_pack(float4 v, float act_scale, uint2& hi, ui
     // Packed conversions (v_cvt_pk_f16_f32), plain C for the low pieces.  NOT h2_low_pair's asm block here: round 4 measured it in
     // this shared epilogue and the heavily spilling conv_h2_kernel<1,1,4,2,32,32> (784 bytes of scratch per lane) then faulted on
     // the head's 64 -> 142 conv -- in the scalar-store path that never executes the block; the plain form of the same arithmetic
-    // does not (scripts/gpu_r4g.sh isolates it).  The fused kernels keep the asm: they do not spill.
+    // does not (scripts/attic/gpu_r4g.sh isolates it).  The fused kernels keep the asm: they do not spill.
     typedef float f32x2_p __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2_p __attribute__((ext_vector_type(2)));
     const f16x2_p h0 = __builtin_convertvector((f32x2_p){x[0], x[1]}, f16x2_p), h1 = __builtin_convertvector((f32x2_p){x[2], x[3]}, f16x2_p);

@@ -1012,7 +1012,7 @@ def test_net_saturation_is_observable(dev):
 
 def test_net_committed_table_all_images_vs_oracle(dev):
     """The EXACT kernels the driver's bench line times (VERDICT r3 weak #1a): romp_amd/tune/romp_hrnet32_f16x2_b32.json installed
-    (it must resolve op for op in this build -- regenerate it with scripts/gpu_r4_tables.sh after changing the plan or the variant
+    (it must resolve op for op in this build -- regenerate it with scripts/gpu_tables.sh after changing the plan or the variant
     list), then ALL 32 images' maps against the oracle (1e-4) and every image's detections against the oracle's parse."""
     import romp_amd
     from romp_amd import tuning
