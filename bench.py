@@ -132,7 +132,7 @@ def roofline_report(net, images, pmc_workload=None):
         roof.update(achieved=round(hbm_gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(hbm_frac, 4))
     else:
         roof.update(achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(mfma_frac, 4))
-    fused = name.startswith('bblock')          # the fused BasicBlock ops run csrc/conv_h2c.hip's kernel in batch plans (16x16x32 MFMAs)
+    fused = name.startswith('bblock')          # the fused BasicBlock ops run csrc/conv_h2c.h's kernel in batch plans (16x16x32 MFMAs)
     if fused:
         roof['kernel_symbol'] = 'romp::bblockr_kernel<%s, 0>' % name[len('bblock'):] + (' (single-image plans: romp::bblock32_kernel<0>)' if name == 'bblock32' else '')
     roof.update(traffic=None,
@@ -440,6 +440,39 @@ def bench_smpl(args, dev):
     print(json.dumps(res), flush=True)
 
 
+def bev_parity_report(model, images, sd, thresh, pick=(0, 7, 19, 31)):
+    """Images `pick` of the timed BEV batch: the 3-D centre / camera maps, the detections and the regressed parameters of the HIP
+    path against the oracle's BEV forward (oracle/bev_oracle.py; the Conv3d refiners make its float32 forward ~1 s per image)."""
+    import numpy as np
+    from oracle import romp_oracle as O, bev_oracle as BO
+    torch.set_num_threads(usable_cores())
+    pick = [p for p in pick if p < images.shape[0]]
+    c3d, cam3d = model.model.localization(images)
+    out = model.model(images)
+    torch.cuda.synchronize()
+    img = images[pick].cpu()
+    co, mo, _ = BO.coarse2fine_localization(sd, O.backbone_forward(sd, img))
+    rep = {'images_compared': pick,
+           'maps_max_abs_vs_oracle': float(max(np.abs(c3d[pick].cpu().numpy() - co.numpy()).max(), np.abs(cam3d[pick].cpu().numpy() - mo.numpy()).max()))}
+    ref = BO.bev_forward(sd, img, thresh)
+    if out is None or ref is None:
+        rep['detections_equal'] = out is None and ref is None
+        return rep
+    b = out['pred_batch_ids'].cpu().numpy()
+    rows = np.concatenate([np.nonzero(b == p)[0] for p in pick])
+
+    def canon(bb, zyx):
+        return np.lexsort(((zyx[:, 0] * 128 + zyx[:, 1]) * 128 + zyx[:, 2], bb))
+    zyx = out['pred_czyxs'].cpu().numpy()[rows]
+    ko, kr = canon(np.searchsorted(pick, b[rows]), zyx), canon(ref['pred_batch_ids'], ref['pred_czyxs'])
+    same = len(rows) == len(ref['pred_batch_ids']) and np.array_equal(zyx[ko], ref['pred_czyxs'][kr])
+    rep['detections_equal'] = bool(same)
+    rep['persons_compared'] = int(len(rows))
+    if same and len(rows):
+        rep['params_pred_max_abs_vs_oracle'] = float(np.abs(out['params_pred'].cpu().numpy()[rows][ko] - ref['params_pred'][kr]).max())
+    return rep
+
+
 def bench_bev(args, dev):
     """BASELINE configs[3]: BEV HRNet-32 + bird's-eye-view head, 512x512, batch 32, 1 GPU (not the headline line)."""
     from romp_amd import bev, synthetic as S
@@ -500,6 +533,8 @@ def bench_bev(args, dev):
                                        'hbm_frac': round(gbs / PEAK_HBM_GBS, 4)}
         res['roofline'] = roof
         res['kernel_classes'] = classes
+    if not args.no_parity:
+        res['config'].update(bev_parity_report(model, images, sd, mid))
     if not args.no_cpu_baseline:
         from oracle import bev_oracle as BO, ref_cpu
         torch.set_num_threads(usable_cores())

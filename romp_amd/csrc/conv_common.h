@@ -64,7 +64,7 @@ constexpr float H2_MAX = 65504.f;
 __device__ __forceinline__ float h2_sat(float x) { return __builtin_fminf(__builtin_fmaxf(x, -H2_MAX), H2_MAX); }
 // Saturation is OBSERVABLE: every site that clamps keeps a per-lane running max of |value before the clamp| (one
 // v_max3_f32 per two values) and reports once per wave and work item -- sat_report -- into the net's device counter
-// (romp_net_saturated; RompNet.saturated).  The two register-resident fused-block kernels (conv_h2b / conv_h2c.hip), whose side work
+// (romp_net_saturated; RompNet.saturated).  The two register-resident fused-block kernels (conv_h2b / conv_h2c.h), whose side work
 // is placed instruction by instruction, count in their checked builds only (romp_net_range_scan and ROMP_CHECK_FINITE=1 run those).
 __device__ __forceinline__ void sat_track(float& mx, float a, float b) { mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))); }
 __device__ __forceinline__ void sat_report(int* counter, float mx) {

@@ -1,4 +1,4 @@
-// conv_fuse.h -- pieces shared by the fused BasicBlock kernels (conv_h2b.hip: 32 channels, conv_h2c.hip: 64 channels)
+// conv_fuse.h -- pieces shared by the fused BasicBlock kernels (conv_h2b.hip: 32 channels, conv_h2c.h: 64 channels)
 #pragma once
 #include "conv_common.h"
 

@@ -19,7 +19,7 @@
 // With one wave per SIMD nothing hides a wave's own stalls and the wave issues in order: every kind of side work is cut into
 // micro-steps of a few instructions, one behind each MFMA, pinned there (sched_barrier); table reads are issued an LDS round trip
 // ahead of their use.  History and measurements: profiles/r03_fused_blocks_notes.md.  Batch plans run the 32-channel blocks on
-// conv_h2c.hip's row-pipelined kernel instead (launch_bblock32 hands over when the ops carry per-wave weight packs); this kernel
+// conv_h2c.h's row-pipelined kernel instead (launch_bblock32 hands over when the ops carry per-wave weight packs); this kernel
 // serves single-image plans.
 #include "conv_split.h"
 #include "conv_fuse.h"
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
 
 // `op` is the block's SECOND conv (its residual is the block input x, its output y); `op1` the first (weights / scale / shift).
 int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
-    {   // two implementations: this file's (v1: 16x16 tiles, one wave per SIMD) and conv_h2c.hip's row-pipelined one (two waves per SIMD)
+    {   // two implementations: this file's (v1: 16x16 tiles, one wave per SIMD) and conv_h2c.h's row-pipelined one (two waves per SIMD)
         // The plan decides (plan.fuse_basic_blocks): the row-pipelined
         // kernel needs the per-wave weight packs, announced by ROMP_OPF_WAVE16 -- weight_aux alone may just as well be the bf16x3 pack
         // of conv_math='all' (a single-image 'all' plan ran the row kernel on bf16x3 bytes).

@@ -1,569 +1,12 @@
-// conv_h2c.hip -- a whole 64- or 32-channel BasicBlock (simple_romp/romp/model.py:54-83) in ONE kernel on the f16x2 split, in the
-// ROW-PIPELINED form:   y = relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x),   C -> C -> C channels, stride 1, H2 tensors in and out.
-// Written for the 64-channel @64^2 class (the network's largest once conv_h2b.hip had fused the 32-channel blocks: 66 launches,
-// 2.75 ms of a 12.2 ms forward at B = 32, 0.29 of the matrix roof as separate convs), then instantiated for 32 channels too, where
-// it runs two workgroups per CU and replaced conv_h2b.hip's kernel in batch plans.  Same idea as there -- x read once (haloed),
-// y written once, the intermediate m never leaves the CU, both convs' weights register-resident -- with the geometry the larger
-// weights force:
-//   * a wave owns a CHANNEL GROUP of 16 output channels of both convs: its share of the split weights is 2 x 72 registers per 32
-//     input channels (C = 64: 288 per wave, one workgroup per CU, ONE wave per SIMD; a wave that owned pixels instead would
-//     need all 2 x 576.  C = 32: 144 per wave, two workgroups per CU).  M = 16 channels means v_mfma_f32_16x16x32_f16: A = 16
-//     channels x 32 input channels (weights, registers), B = 32 input channels x 16 pixels (an LDS fragment), D = 4 consecutive
-//     channels of one pixel per lane.  C = 64: four channel groups, every wave walks all rows of the tile; C = 32: two channel groups
-//     x two ROW GROUPS (m rows 0..4 / 5..9 in conv1, output rows 0..3 / 4..7 in conv2);
-//   * tiles of 8 x 16 output pixels: 12 x 20 input halo (C = 64: 60 KB in LDS), 10 x 18 halo of m (48 KB);
-//   * a pixel block is 16 pixels of ONE ROW, and input rows are walked top to bottom: the fragment of (input row R, column shift
-//     dx) feeds the output rows R, R - 1, R - 2 (dy = 0, 1, 2) -- 2 LDS reads per 9 MFMAs -- and a row of m (of y) is complete two
-//     input rows later, so its hand-over (finish) rides under the MFMAs of the following row: no block slots, no tail but the
-//     last row.  The two edge columns of m (10 rows x {0, 17}) are two extra blocks, done first;
-//   * LDS in PLANES: plane (octet o, piece) holds one 16-byte unit per pixel, planes a multiple of 16 units apart: the 16 lanes of
-//     a ds_read_b128 group then read 16 different pixels' units at consecutive unit addresses whatever octets they are after
-//     (bank group = unit address mod 16): conflict-free for every tap; one base register + immediates address every fragment;
-//   * scale / shift of a lane's 4 channels live in registers (no tables); the residual is parked per lane in LDS as in
-//     conv_h2b.hip; the next tile's halo arrives by raw-buffer LDS-DMA under conv2; the last output row of a tile is finished
-//     under the next tile's first MFMAs.
-// ConvParams as used here: in = x (H2), res = x, out = y (H2); w3 = conv1's weights REPACKED per channel group ([group C/16][tap 9]
-// [k-chunk C/32][piece 2][lane 64] 16-byte units, plan.pack_h2_wave16), wh = conv2's; scale / w = conv1's f16x2 scale and shift
-// (C floats each), scale_h / shift = conv2's; the geometry fields as for a conv.
-#include "conv_split.h"
-#include "conv_fuse.h"
-#include <string.h>
+// conv_h2c.hip -- the 64-channel instantiation of the row-pipelined fused BasicBlock kernel (conv_h2c.h; the 32-channel one is
+// conv_h2c32.hip: seven builds of a 270-MFMA hand-scheduled kernel per channel count are the longest compile of the library, the two
+// translation units halve the build's critical path).
+#include "conv_h2c.h"
 
 namespace romp {
 
-// Geometry for C channels.  C = 64: four channel groups of 16, each wave all rows (one workgroup per CU: 288 weight registers per
-// wave).  C = 32 (the two-waves-per-SIMD form of the 32-channel block): two channel groups x two ROW groups -- wave (cg, t) does
-// m rows 5 t .. 5 t + 4 of conv1 and output rows 4 t .. 4 t + 3 of conv2 -- 144 weight registers per wave, 71 KB of LDS: two
-// workgroups per CU, each other's MFMAs covering each other's side work.
-template <int C>
-struct RCfg {
-    static constexpr int TH = 8, TW = 16;
-    static constexpr int IR = TH + 4, IC = TW + 4;             // input halo 12 x 20
-    static constexpr int MR = TH + 2, MC = TW + 2;             // intermediate halo 10 x 18
-    static constexpr int XPL = IR * IC;                        // units per input plane: 240 (= 0 mod 16)
-    static constexpr int MPL = 192;                            // units per m plane: 180 used, padded to 0 mod 16
-    static constexpr int NPL = C / 4;                          // planes: C / 8 octets x {high, low}; plane = 2 * octet + piece
-    static constexpr int NKC = C / 32;                         // 32-input-channel chunks (one MFMA's K)
-    static constexpr int NCG = C / 16, NRG = 4 / NCG;          // channel groups of 16 output channels; row groups
-    static constexpr int MRW = MR / NRG, THW = TH / NRG;       // m rows / output rows per wave
-    static constexpr int IRW = MRW + 2, MRW2 = THW + 2;        // input rows a wave walks in conv1; m rows in conv2
-    static constexpr int NEB = 2 / NRG;                        // edge blocks per wave
-    static constexpr int NPIECE = NPL * XPL / 64;              // DMA pieces (64 units): 60 / 30
-    static constexpr int NI = (NPIECE + 3) / 4;                // per wave: 15 / 8 (the last one only for waves 0, 1 when C = 32)
-    static constexpr int OFF_M = NPL * XPL * 16;
-    static constexpr int OFF_R = OFF_M + NPL * MPL * 16;       // residual parking, [wave][row THW][piece 2][lane] x 8 bytes
-    static constexpr int LDS_BYTES = OFF_R + 4 * 2 * THW * 64 * 8 + 64;
-    static constexpr int WG_PER_CU = C == 32 ? 2 : 1;
-    static_assert(C == 32 || C == 64, "32 or 64 channels");
-    static_assert(XPL % 16 == 0 && MPL % 16 == 0 && MPL >= MR * MC, "planes a multiple of 16 units apart");
-    static_assert(NPL * XPL % 64 == 0, "whole DMA pieces");
-    static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS of a CU");
-};
-
-typedef float f32x4c __attribute__((ext_vector_type(4)));
-
-// DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / parking, 4 no finish, 8 no MFMA;
-// 16: the CHECKED build (correct outputs): also counts values clamped at +-65504 on their way into fp16 pieces (conv_common.h
-// sat_report; romp_net_range_scan and ROMP_CHECK_FINITE=1 run it -- two more VALU per four values of side work)
-template <int C, int DBG>
-__global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvParams p) {
-    using X = RCfg<C>;
-    using frag = f16x8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* sBuf = reinterpret_cast<char*>(smem);
-    const unsigned lds0 = (unsigned)(unsigned long long)(lds_void_f*)sBuf;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = wv % X::NCG, tg = wv / X::NCG;              // this wave's channel group and row group
-    const int px = lane & 15, q = lane >> 4;                   // B / D operand: pixel px of the block; A: channel px; k-quarter (D: channel quad) q
-    int tr_n = 0;                                              // phase stamps (ROMP_CONV_TRACE=1): 1 entry, 4 set-up done, per tile 11 conv1 MFMAs,
-    constexpr int tr_wpw = 4;                                  // 13 last hand-over, 12 barrier, 17 conv2 MFMAs, 15 barrier
-    ROMP_TRACE(1);
-    const int qx = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
-    const int nwg_q = gridDim.x / p.n_queues;
-    const int j0 = blockIdx.x / p.n_queues;
-    if (j0 >= p.per_queue) return;
-    const int n_mine = (p.per_queue - j0 + nwg_q - 1) / nwg_q;
-    auto tile_of = [&](int k) __attribute__((always_inline)) { return decode_item(p, qx, j0 + k * nwg_q, 32); };
-
-    // scale / shift of this lane's 4 channels (16 wv + 4 q ..), PRE-MULTIPLIED by 2^act_shift: m and y are produced in the scaled
-    // domain the H2 pieces live in (ReLU commutes with the positive factor; the residual's pieces are x * 2^act_shift already)
-    f32x4c s1, b1, s2, b2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = 16 * cg + 4 * q + i;
-        s1[i] = p.scale[c] * p.act_scale;   b1[i] = p.w[c] * p.act_scale;
-        s2[i] = p.scale_h[c] * p.act_scale; b2[i] = p.shift[c] * p.act_scale;
-    }
-
-    // ---- halo DMA: piece 4 k + wv is this wave's k-th; a lane's unit U = 64 piece + lane -> plane U / 240, pixel U % 240
-    typedef int i32x4_t __attribute__((ext_vector_type(4)));
-    int d_rc[X::NI], d_off[X::NI];                             // row | col << 8;  byte offset from the halo origin
-#pragma unroll
-    for (int k = 0; k < X::NI; ++k) {
-        const int U = (k * 4 + wv) * 64 + lane;
-        const int plane = U / X::XPL, r = U % X::XPL;
-        const int row = r / X::IC, col = r % X::IC;
-        d_rc[k] = row | (col << 8);
-        d_off[k] = ((row * p.W + col) * p.in_cs + (plane >> 1) * 8 + (plane & 1) * 4) * 4;
-    }
-    i32x4_t rsrc;                                              // the input tensor as a raw buffer: offsets beyond num_records read zeros
-    {
-        const unsigned long long base = (unsigned long long)(p.in + p.in_co);
-        rsrc[0] = (int)(unsigned)base;
-        rsrc[1] = (int)(unsigned)(base >> 32) & 0xffff;
-        rsrc[2] = (int)p.in_bytes;
-        rsrc[3] = 0x00020000;
-    }
-    auto is_interior = [&](const Item& it) __attribute__((always_inline)) { return it.ty > 0 && it.ty < p.tiles_y - 1 && it.tx > 0 && it.tx < p.tiles_x - 1; };
-    auto fetch_piece = [&](const Item& it, bool valid, bool interior, int kk) __attribute__((always_inline)) {
-        if (DBG & 1) return;
-        if (!valid || kk * 4 + wv >= X::NPIECE) return;        // (uniform)
-        const int iy0 = it.ty * X::TH - 2, ix0 = it.tx * X::TW - 2;
-        const int origin = ((it.b * p.H + iy0) * p.W + ix0) * p.in_cs * 4;     // may be "negative": the sum with d_off is not
-        const unsigned dst = lds0 + (unsigned)((kk * 4 + wv) * 1024);
-        int voff = d_off[kk] + origin;
-        if (!interior) {
-            int rc = d_rc[kk];
-            asm volatile("" : "+v"(rc));
-            const int iy = iy0 + (rc & 255), ix = ix0 + (rc >> 8);
-            const int ok = (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
-            voff = ok ? voff : (int)0x80000000;
-        }
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(dst) : "memory");
-    };
-
-    // ---- LDS addresses (bytes).  Input plane unit (plane, row, col) = plane * 240 + row * 20 + col; m: OFF_M + plane * 192 + row * 18 + col
-    // fragment of a row block: lane (px, q) reads octet 4 kc + q, piece pc of the pixel dx columns right of its own: base + immediates
-    // (conv1's blocks are m columns 1..16 = input columns 1 + px + dx; conv2's are output columns px = m columns px + dx)
-    const int xa = (2 * q * X::XPL + tg * X::MRW * X::IC + 1 + px) * 16;   // + ((8 kc + pc) * 240 + Rl * 20 + dx) * 16, Rl: the wave's local row
-    const int ma = X::OFF_M + (2 * q * X::MPL + tg * X::THW * X::MC + px) * 16;   // + ((8 kc + pc) * 192 + Rl * 18 + dx) * 16
-    // the two edge blocks of conv1: m pixels (row, col in {0, 17}); E0 rows 0..7 (lane px -> row px / 2, col 17 (px & 1)), E1 rows 8, 9 (px < 4)
-    const int e_row = px >> 1, e_col = (px & 1) * 17;
-    const bool e1_act = px < 4;
-    const int xe0 = (2 * q * X::XPL + e_row * X::IC + e_col) * 16;                         // + ((8 kc + pc) * 240 + dy * 20 + dx) * 16
-    const int xe1 = (2 * q * X::XPL + (e1_act ? 8 + e_row : 8) * X::IC + (e1_act ? e_col : 0)) * 16;
-    // hand-over stores: lane (px, q) holds channels 16 wv + 4 q .. + 3 = half (q & 1) of octet 2 wv + q / 2
-    const int mo = 2 * cg + (q >> 1);
-    const int hs = X::OFF_M + (2 * mo * X::MPL + tg * X::MRW * X::MC + 1 + px) * 16 + (q & 1) * 8;   // row block: + (pc * 192 + rl * 18) * 16
-    const int hse0 = X::OFF_M + (2 * mo * X::MPL + e_row * X::MC + e_col) * 16 + (q & 1) * 8;   // + pc * 192 * 16  (E1: + 8 * 18 * 16)
-    // the residual x of output pixel (r, px) in the input halo: pixel (r + 2, px + 2), same octet half
-    const int ra = (2 * mo * X::XPL + (2 + tg * X::THW) * X::IC + 2 + px) * 16 + (q & 1) * 8;   // + (pc * 240 + rl * 20) * 16
-    char* sR = sBuf + X::OFF_R + (wv * 2 * X::THW * 64 + lane) * 8;   // this lane's parking slots: + (rl * 2 + pc) * 512
-
-    Item it = tile_of(0);
-#pragma unroll
-    for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, kk);
-    // ---- this wave's weights (asked for AFTER the first halo: both trips overlap): 16 output channels x 64 input channels x 9 taps x 2 pieces of each conv
-    frag w1[9][X::NKC][2], w2[9][X::NKC][2];                   // [tap][k-chunk of 32 input channels][piece]
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int kc = 0; kc < X::NKC; ++kc)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                w1[tap][kc][pc] = __builtin_bit_cast(frag, p.w3[(((cg * 9 + tap) * X::NKC + kc) * 2 + pc) * 64 + lane]);
-                w2[tap][kc][pc] = __builtin_bit_cast(frag, p.wh[(((cg * 9 + tap) * X::NKC + kc) * 2 + pc) * 64 + lane]);
-            }
-    // a "use" of every weight register in front of the tile loop: hipcc waits for these loads HERE, once; the halo DMAs (invisible to
-    // it) are covered by the explicit wait.  conv1's weights are pinned to AGPRs (MFMA reads them there), conv2's stay in VGPRs.
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int kc = 0; kc < X::NKC; ++kc)
-            asm volatile("" : "+a"(w1[tap][kc][0]), "+a"(w1[tap][kc][1]), "+v"(w2[tap][kc][0]), "+v"(w2[tap][kc][1]));
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    ROMP_TRACE(4);
-
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-    auto pack_hi = [&](float a, float b) __attribute__((always_inline)) {
-        const f32x2_t v = {a, b};
-        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
-    };
-    // micro-steps [lo, hi) of N for MFMA number g of G: spread evenly
-    auto share = [](int g, int G, int N, int& lo, int& hi) __attribute__((always_inline)) { lo = g * N / G; hi = (g + 1) * N / G; };
-#define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
-
-    f32x4c acc2[X::THW];                                        // (the last row's outlives its tile: finished under the next tile's first MFMAs)
-    float sat_mx = 0.f;                                         // (DBG & 16) largest value handed to a split: == H2_MAX iff clamped
-    Item itp = it;
-#pragma unroll 1
-    for (int k = 0; k < n_mine; ++k) {
-        const bool has_next = k + 1 < n_mine;
-        const Item itn = has_next ? tile_of(k + 1) : it;
-        const bool next_interior = is_interior(itn);
-
-        // ---- the finish of an output row: bn2 + x + ReLU in the scaled domain, split; lanes (px, q) and (px, q ^ 1) trade halves
-        // (v_permlane16_swap) so that each stores one whole 16-byte unit.  9 micro-steps.
-        uint2 e_rh, e_rl;
-        float ev[4];
-        unsigned eh[2], el[2];
-        int e_o = 0;
-        constexpr int FIN_N = 9;
-        auto fin_micro = [&](const Item& tl, bool live, int r, int t) __attribute__((always_inline)) {
-            if (DBG & 4) return;
-            switch (t) {
-            case 0:
-                e_rh = *reinterpret_cast<const uint2*>(sR + (r * 2 + 0) * 512);
-                e_rl = *reinterpret_cast<const uint2*>(sR + (r * 2 + 1) * 512);
-                break;
-            case 1: case 2: case 3: case 4: {
-                const int e = t - 1;
-                const unsigned wh = e < 2 ? e_rh.x : e_rh.y, wl = e < 2 ? e_rl.x : e_rl.y;
-                const float v = fmaf(acc2[r][e], s2[e], b2[e]);
-                ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
-                if ((DBG & 16) && live) sat_mx = fmaxf(sat_mx, ev[e]);      // (not live: the first tile's pass over a row that does not exist)
-                break; }
-            case 5: eh[0] = pack_hi(ev[0], ev[1]); eh[1] = pack_hi(ev[2], ev[3]); break;
-            case 6: el[0] = h2_low_pair(eh[0], ev[0], ev[1]); el[1] = h2_low_pair(eh[1], ev[2], ev[3]); break;
-            case 7: {
-                // lanes (px, q even) and (px, q odd) hold channels .. + 0..3 and .. + 4..7 of an octet: after the swaps the even one
-                // holds the octet's 8 high pieces, the odd one its 8 low pieces
-                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                const u32x2_t a = __builtin_amdgcn_permlane16_swap(eh[0], el[0], false, false);
-                const u32x2_t b = __builtin_amdgcn_permlane16_swap(eh[1], el[1], false, false);
-                eh[0] = a[0]; el[0] = a[1]; eh[1] = b[0]; el[1] = b[1];
-                const int oy = tl.ty * X::TH + tg * X::THW + r, ox = tl.tx * X::TW + px;
-                e_o = (oy * p.out_rs + ox * p.out_cs) + (16 * cg + 4 * q);
-                break; }
-            default: {
-                float* o = p.out + (size_t)tl.b * p.out_bs + p.out_co + (unsigned)e_o;
-                if (live) *reinterpret_cast<uint4*>(o) = make_uint4(eh[0], eh[1], el[0], el[1]);
-                break; }
-            }
-        };
-        // ---- residual parking: 16 copies (row r, piece pc) from the input halo, read at step i, written three steps later
-        uint2 pk[4];
-        constexpr int PARK_N = 2 * X::THW + 3;
-        auto park_micro = [&](int t) __attribute__((always_inline)) {
-            if (DBG & 2) return;
-            if (t < 2 * X::THW) pk[t % 4] = *reinterpret_cast<const uint2*>(sBuf + ra + ((t & 1) * X::XPL + (t >> 1) * X::IC) * 16);
-            if (t >= 3) *reinterpret_cast<uint2*>(sR + (t - 3) * 512) = pk[(t - 3) % 4];
-        };
-        // ---- the hand-over of a block of m (4 channels of one pixel per lane): bn1 + ReLU, zero outside the image (conv2's padding),
-        // split, into the m planes.  6 micro-steps.  `inside`: is this lane's m pixel inside the image
-        float hv[4];
-        unsigned hh[2], hl[2];
-        constexpr int HAND_N = 6;
-        auto hand_micro = [&](const f32x4c& a, bool inside, bool act, int addr, int t) __attribute__((always_inline)) {
-            if (DBG & 2) return;
-            switch (t) {
-            case 0: case 1: {
-#pragma unroll
-                for (int e = 2 * t; e < 2 * t + 2; ++e) {
-                    const float v = h2_sat(fmaxf(fmaf(a[e], s1[e], b1[e]), 0.f));
-                    if ((DBG & 16) && inside) sat_mx = fmaxf(sat_mx, v);
-                    hv[e] = inside ? v : 0.f;
-                }
-                break; }
-            case 2: hh[0] = pack_hi(hv[0], hv[1]); hh[1] = pack_hi(hv[2], hv[3]); break;
-            case 3: hl[0] = h2_low_pair(hh[0], hv[0], hv[1]); hl[1] = h2_low_pair(hh[1], hv[2], hv[3]); break;
-            case 4: if (act) *reinterpret_cast<uint2*>(sBuf + addr) = make_uint2(hh[0], hh[1]); break;
-            default: if (act) *reinterpret_cast<uint2*>(sBuf + addr + X::MPL * 16) = make_uint2(hl[0], hl[1]); break;
-            }
-        };
-        const int iy_m0 = it.ty * X::TH - 1 + tg * X::MRW;     // image row of this wave's m row 0
-        // this wave's edge block(s): block e covers m rows 8 e + (px >> 1) (e = 1: lanes px < 4 only), columns {0, 17}
-        auto edge_no = [&](int i) __attribute__((always_inline)) { return X::NEB == 2 ? i : tg; };   // (uniform)
-        const int ix_e = it.tx * X::TW - 1 + e_col;             // image column of this lane's edge-block pixel
-
-        // ================= 1. conv1
-        f32x4c accE[X::NEB], acc1[X::MRW];
-#pragma unroll
-        for (int e = 0; e < X::NEB; ++e)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) accE[e][i] = 0.f;
-#pragma unroll
-        for (int r = 0; r < X::MRW; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc1[r][i] = 0.f;
-        {
-            // fragment reads run PF units (a unit = the MFMAs fed by one fragment pair) ahead of their MFMAs.  Units 0 .. NUE - 1: the
-            // edge block(s), unit (tap * NKC + kc) * NEB + e; then the row-block fragments of the wave's input rows,
-            // NUE + ((Rl * 3 + dx) * NKC + kc)
-            constexpr int PF = C == 32 ? 2 : 3, NUE = 9 * X::NKC * X::NEB, NU = NUE + X::IRW * 3 * X::NKC, RING = PF + X::NEB;
-            frag xf[RING][2];
-            const int xe = (edge_no(0) == 0 ? xe0 : xe1);
-            auto read_x = [&](int u) __attribute__((always_inline)) {
-#pragma unroll
-                for (int pc = 0; pc < 2; ++pc) {
-                    if (u < NUE) {
-                        const int e = u % X::NEB, kc = (u / X::NEB) % X::NKC, tap = u / (X::NEB * X::NKC);
-                        const int base = X::NEB == 2 ? (e ? xe1 : xe0) : xe;
-                        xf[u % RING][pc] = *reinterpret_cast<const frag*>(sBuf + base + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
-                    } else {
-                        const int v = u - NUE, Rl = v / (3 * X::NKC), dx = (v / X::NKC) % 3, kc = v % X::NKC;
-                        xf[u % RING][pc] = *reinterpret_cast<const frag*>(sBuf + xa + ((8 * kc + pc) * X::XPL + Rl * X::IC + dx) * 16);
-                    }
-                }
-            };
-#pragma unroll
-            for (int u = 0; u < PF; ++u) read_x(u);
-            // (a) the edge block(s): no row reuse.  Under them: the previous tile's last output row, then this tile's residual parking
-            constexpr int GE = NUE * 3, NE = FIN_N + PARK_N;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int kc = 0; kc < X::NKC; ++kc) {
-                    const int u = (tap * X::NKC + kc) * X::NEB;    // units u .. u + NEB - 1: with two blocks their MFMAs take turns
-#pragma unroll
-                    for (int e = 0; e < X::NEB; ++e)
-                        if (u + e + PF < NU) read_x(u + e + PF);
-#pragma unroll
-                    for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                        for (int e = 0; e < X::NEB; ++e) {
-                            const frag (&x)[2] = xf[(u + e) % RING];
-                            if (!(DBG & 8))
-                                accE[e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], accE[e], 0, 0, 0);
-                            const int g = ((tap * X::NKC + kc) * 3 + pr) * X::NEB + e;
-                            int lo, hi;
-                            share(g, GE, NE, lo, hi);
-#pragma unroll
-                            for (int t = lo; t < hi; ++t) { if (t < FIN_N) fin_micro(itp, k > 0, X::THW - 1, t); else park_micro(t - FIN_N); }
-                            SIDE_PIN();
-                        }
-                }
-            // (b) the row blocks, input row after input row (Rl: local to the wave's row group).  Under input row Rl: the hand-over of
-            // the edge block(s) (Rl < NEB), then of m row Rl - 3 (complete since input row Rl - 1)
-#pragma unroll
-            for (int Rl = 0; Rl < X::IRW; ++Rl) {
-                const int dy_lo = Rl - (X::MRW - 1) > 0 ? Rl - (X::MRW - 1) : 0, dy_hi = Rl < 2 ? Rl : 2;     // m rows Rl - dy in [0, MRW)
-                const int nv = dy_hi - dy_lo + 1;
-                const int G = 3 * X::NKC * nv * 3;
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                    for (int kc = 0; kc < X::NKC; ++kc) {
-                        const int u = NUE + (Rl * 3 + dx) * X::NKC + kc;
-                        if (u + PF < NU) read_x(u + PF);
-                        const frag (&x)[2] = xf[u % RING];
-#pragma unroll
-                        for (int pr = 0; pr < 3; ++pr)          // (products outside, rows inside: consecutive MFMAs on different accumulators)
-#pragma unroll
-                            for (int dy = dy_lo; dy <= dy_hi; ++dy) {
-                                const int tap = dy * 3 + dx;
-                                if (!(DBG & 8))
-                                    acc1[Rl - dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], acc1[Rl - dy], 0, 0, 0);
-                                const int g = (((dx * X::NKC + kc) * 3) + pr) * nv + (dy - dy_lo);
-                                int lo, hi;
-                                share(g, G, HAND_N, lo, hi);
-#pragma unroll
-                                for (int t = lo; t < hi; ++t) {
-                                    if (Rl < X::NEB) {
-                                        const int e = edge_no(Rl);
-                                        const bool act = e == 0 || e1_act;
-                                        const int iy = it.ty * X::TH - 1 + 8 * e + e_row;
-                                        const bool in = act && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix_e < (unsigned)p.Wo;
-                                        hand_micro(accE[Rl], in, act, hse0 + e * (8 * X::MC * 16), t);
-                                    } else if (Rl >= 3) {
-                                        const int rl = Rl - 3;
-                                        // (only a wave's first and last m row can lie outside the image: above it / below it)
-                                        hand_micro(acc1[rl], rl == 0 ? iy_m0 >= 0 : true, true, hs + rl * X::MC * 16, t);
-                                    }
-                                }
-                                SIDE_PIN();
-                            }
-                    }
-            }
-            ROMP_TRACE(11);
-            if (DBG & 2) {                                     // (knock-out builds: keep every MFMA)
-#pragma unroll
-                for (int r = 0; r < X::MRW; ++r) asm volatile("" :: "v"(acc1[r]));
-#pragma unroll
-                for (int e = 0; e < X::NEB; ++e) asm volatile("" :: "v"(accE[e]));
-            }
-#pragma unroll
-            for (int t = 0; t < HAND_N; ++t) hand_micro(acc1[X::MRW - 1], (unsigned)(iy_m0 + X::MRW - 1) < (unsigned)p.Ho, true, hs + (X::MRW - 1) * X::MC * 16, t);
-            ROMP_TRACE(13);
-        }
-        // ---- 2. every wave is done with the input halo and m is complete
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        ROMP_TRACE(12);
-
-        // ================= 3. conv2 from m, m row after m row (local rows again).  Under m row Rl: a share of the next tile's halo DMA
-        // and the finish of output row Rl - 3 (complete since m row Rl - 1); the wave's last output row waits for the next tile
-#pragma unroll
-        for (int r = 0; r < X::THW; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc2[r][i] = 0.f;
-        constexpr int PF2 = 2, NU2 = X::MRW2 * 3 * X::NKC;       // unit (Rl * 3 + dx) * NKC + kc
-        frag xg[PF2 + 1][2];
-        auto read_m = [&](int u) __attribute__((always_inline)) {
-            const int Rl = u / (3 * X::NKC), dx = (u / X::NKC) % 3, kc = u % X::NKC;
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
-                xg[u % (PF2 + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + ma + ((8 * kc + pc) * X::MPL + Rl * X::MC + dx) * 16);
-        };
-#pragma unroll
-        for (int u = 0; u < PF2; ++u) read_m(u);
-#pragma unroll
-        for (int Rl = 0; Rl < X::MRW2; ++Rl) {
-            const int dy_lo = Rl - (X::THW - 1) > 0 ? Rl - (X::THW - 1) : 0, dy_hi = Rl < 2 ? Rl : 2;        // output rows Rl - dy in [0, THW)
-            const int nv = dy_hi - dy_lo + 1;
-            const int G = 3 * X::NKC * nv * 3;
-            // this row's share of the DMA pieces: all of them under the first half of the rows (the last ones need time to land
-            // before the barrier at the end of the tile)
-            constexpr int FR = (X::MRW2 + 1) / 2;
-            const int f_lo = Rl < FR ? Rl * X::NI / FR : X::NI, f_hi = Rl < FR ? (Rl + 1) * X::NI / FR : X::NI;
-            const int NS = (Rl >= 3 ? FIN_N : 0) + (f_hi - f_lo);
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-                for (int kc = 0; kc < X::NKC; ++kc) {
-                    const int u = (Rl * 3 + dx) * X::NKC + kc;
-                    if (u + PF2 < NU2) read_m(u + PF2);
-                    const frag (&x)[2] = xg[u % (PF2 + 1)];
-#pragma unroll
-                    for (int pr = 0; pr < 3; ++pr)
-#pragma unroll
-                        for (int dy = dy_lo; dy <= dy_hi; ++dy) {
-                            const int tap = dy * 3 + dx;
-                            if (!(DBG & 8))
-                                acc2[Rl - dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], acc2[Rl - dy], 0, 0, 0);
-                            const int g = (((dx * X::NKC + kc) * 3) + pr) * nv + (dy - dy_lo);
-                            int lo, hi;
-                            share(g, G, NS, lo, hi);
-#pragma unroll
-                            for (int t = lo; t < hi; ++t) {
-                                if (t < f_hi - f_lo) fetch_piece(itn, has_next, next_interior, f_lo + t);
-                                else fin_micro(it, true, Rl - 3, t - (f_hi - f_lo));
-                            }
-                            SIDE_PIN();
-                        }
-                }
-        }
-        ROMP_TRACE(17);
-        if (DBG & 4) {
-#pragma unroll
-            for (int r = 0; r < X::THW; ++r) asm volatile("" :: "v"(acc2[r]));
-        }
-        // ---- 4. the next halo has landed, for every wave; m may be overwritten
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        ROMP_TRACE(15);
-        itp = it;
-        it = itn;
-    }
-    if (!(DBG & 4)) {                                          // the last tile's last output row
-        const int r = X::THW - 1;
-        const uint2 rh = *reinterpret_cast<const uint2*>(sR + (r * 2 + 0) * 512), rl = *reinterpret_cast<const uint2*>(sR + (r * 2 + 1) * 512);
-        float ev[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned wh = e < 2 ? rh.x : rh.y, wl = e < 2 ? rl.x : rl.y;
-            const float v = fmaf(acc2[r][e], s2[e], b2[e]);
-            ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
-            if (DBG & 16) sat_mx = fmaxf(sat_mx, ev[e]);
-        }
-        unsigned eh[2] = {pack_hi(ev[0], ev[1]), pack_hi(ev[2], ev[3])};
-        unsigned el[2] = {h2_low_pair(eh[0], ev[0], ev[1]), h2_low_pair(eh[1], ev[2], ev[3])};
-        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-        const u32x2_t a = __builtin_amdgcn_permlane16_swap(eh[0], el[0], false, false);
-        const u32x2_t b = __builtin_amdgcn_permlane16_swap(eh[1], el[1], false, false);
-        const int oy = itp.ty * X::TH + tg * X::THW + r, ox = itp.tx * X::TW + px;
-        float* o = p.out + (size_t)itp.b * p.out_bs + p.out_co + (unsigned)((oy * p.out_rs + ox * p.out_cs) + (16 * cg + 4 * q));
-        *reinterpret_cast<uint4*>(o) = make_uint4(a[0], b[0], a[1], b[1]);
-    }
-    if (DBG & 16) sat_report(p.sat, sat_mx);
-#undef SIDE_PIN
-}
-
-// `op` is the block's SECOND conv (its residual is the block input x, its output y); `op1` the first.  Their per-wave weight packs
-// (plan.pack_h2_wave16) are in `weight_aux`.
-template <int C>
-static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
-    using X = RCfg<C>;
-    ROMP_REQUIRE(op.ksize == 3 && op.stride == 1 && op.Cin == C && op.Cout == C && op.groups == 1 &&
-                 op1.ksize == 3 && op1.stride == 1 && op1.Cin == C && op1.Cout == C && op1.groups == 1,
-                 "bblock%d: two 3x3 stride-1 %d -> %d convs expected", C, C, C);
-    ROMP_REQUIRE(op1.weight_aux && op1.scale_h2 && op.weight_aux && op.scale_h2 && (op1.flags & op.flags & ROMP_OPF_WAVE16) && op1.relu && op.relu,
-                 "bblock%d: per-wave f16x2 weight packs (ROMP_OPF_WAVE16) and ReLUs expected", C);
-    ROMP_REQUIRE(op1.in_fmt == ROMP_FMT_H2 && op.res_fmt == ROMP_FMT_H2 && op.out_fmt == ROMP_FMT_H2 && op1.act_shift == op.act_shift,
-                 "bblock%d: H2 tensors expected", C);
-    ROMP_REQUIRE(op.H % X::TH == 0 && op.W % X::TW == 0 && op1.H == op.H && op1.W == op.W, "bblock%d: %dx%d is not a multiple of the 8x16 tile", C, op.H, op.W);
-    ROMP_REQUIRE(op1.in_cstride == op.res_cstride && op1.in_coff == op.res_coff && ((op1.in_cstride | op1.in_coff | op.out_cstride | op.out_coff) & 7) == 0,
-                 "bblock%d: the residual must be the block input, octet aligned", C);
-    static bool attr = false;
-    static int num_cu = 256;
-    using KernelFn = void (*)(ConvParams);
-    static KernelFn fn = bblockr_kernel<C, 0>;
-    const KernelFn fn_checked = bblockr_kernel<C, 16>;
-    if (!attr) {                                               // (romp_net_create calls this path's set-up outside any stream capture)
-        const char* e = getenv("ROMP_CONV_DEBUG");
-        switch (e ? atoi(e) : 0) {
-            case 0: break;
-            case 1: fn = bblockr_kernel<C, 1>; break;
-            case 2: fn = bblockr_kernel<C, 2>; break;
-            case 4: fn = bblockr_kernel<C, 4>; break;
-            case 7: fn = bblockr_kernel<C, 7>; break;
-            case 8: fn = bblockr_kernel<C, 8>; break;
-            default: ROMP_REQUIRE(false, "bblock%d: ROMP_CONV_DEBUG is one of 0 1 2 4 7 8 here", C);
-        }
-        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
-        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_checked), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ROMP_HIP_CHECK(hipGetDevice(&dev));
-        ROMP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        attr = true;
-    }
-    if (x == nullptr && y == nullptr) return ROMP_OK;          // set-up only
-    ConvParams p;
-    memset(&p, 0, sizeof(p));
-    p.in = x; p.res = x; p.out = y;
-    p.w3 = reinterpret_cast<const uint4*>(op1.weight_aux);
-    p.wh = reinterpret_cast<const uint4*>(op.weight_aux);
-    p.scale = op1.scale_h2; p.w = op1.shift;
-    p.scale_h = op.scale_h2; p.shift = op.shift;
-    p.act_scale = ldexpf(1.f, op.act_shift);
-    p.inv_act_scale = ldexpf(1.f, -op.act_shift);
-    p.in_h2 = p.out_h2 = p.res_h2 = 1;
-    p.queue = queue;
-    p.trace = conv_trace_arm(st);
-    p.sat = conv_sat_counter();
-    const bool checked = conv_sat_checked() && p.sat && fn == static_cast<KernelFn>(bblockr_kernel<C, 0>);
-    {
-        const unsigned long long bytes = ((unsigned long long)B * op.H * op.W * op1.in_cstride - op1.in_coff) * 4ull;
-        ROMP_REQUIRE(bytes < 0x80000000ull, "bblock%d: input tensor of %llu bytes: beyond the 31-bit offsets of the halo fetch", C, bytes);
-        p.in_bytes = (unsigned)bytes;
-    }
-    p.H = p.Ho = op.H; p.W = p.Wo = op.W;
-    p.Cout = C; p.cin_valid = C; p.cin_pad = C; p.cout_pad = C;
-    p.in_cs = op1.in_cstride; p.in_co = op1.in_coff;
-    p.out_cs = op.out_cstride; p.out_co = op.out_coff;
-    p.res_cs = op.res_cstride; p.res_co = op.res_coff;
-    p.relu = 1;
-    p.tiles_x = op.W / X::TW; p.tiles_y = op.H / X::TH; p.tiles_total = B * p.tiles_x * p.tiles_y;
-    p.nslices = p.ns_total = 1;
-    p.n_queues = (p.tiles_total % 8 == 0) ? 8 : 1;
-    p.per_queue = p.tiles_total / p.n_queues;
-    p.vec_io = 1;
-    p.pad_h = p.pad_w = 1;
-    p.out_rs = op.out_rstride > 0 ? op.out_rstride : p.Wo * op.out_cstride;
-    p.out_bs = op.out_bstride > 0 ? op.out_bstride : p.Ho * p.Wo * op.out_cstride;
-    const int cap = conv_wg_cap();
-    long grid = (long)num_cu * ((cap > 0 && cap < X::WG_PER_CU) ? cap : X::WG_PER_CU);
-    if (grid > p.tiles_total) grid = p.tiles_total;
-    if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(checked ? fn_checked : fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
-    ROMP_HIP_CHECK(hipGetLastError());
-    return ROMP_OK;
-}
-
 int launch_bblock64(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
     return launch_bblockr<64>(op1, op, x, y, B, queue, st);
-}
-// the 32-channel block in the same row-pipelined form, two workgroups per CU (conv_h2b.hip's launch_bblock32 hands over to it when
-// the ops carry per-wave weight packs)
-int launch_bblock32r(const romp_op& op1, const romp_op& op, const float* x, float* y, int B, int* queue, hipStream_t st) {
-    return launch_bblockr<32>(op1, op, x, y, B, queue, st);
 }
 
 }  // namespace romp

@@ -5,7 +5,7 @@
 // Both are 1x1 convs on 256-channel 128^2 tensors and HBM-bound (4.3-4.5 TB/s as separate launches, 1.7 ms of an 11.8 ms forward
 // at B = 32); t has to be written anyway (it is the next block's residual) but need not be READ back: 1.87 -> 1.34 GB per seam.
 // No halo (1x1): a tile is 64 consecutive pixels of the flattened batch.  One 256-thread workgroup per CU, one wave per SIMD;
-// 16-channel MFMA rows as in conv_h2c.hip (v_mfma_f32_16x16x32_f16): GEMM 1, wave w computes channel groups 4 w .. 4 w + 3 of
+// 16-channel MFMA rows as in conv_h2c.h (v_mfma_f32_16x16x32_f16): GEMM 1, wave w computes channel groups 4 w .. 4 w + 3 of
 // t for the tile's four 16-pixel blocks from m in LDS (planes, DMA); its epilogue adds the residual (prefetched into registers a
 // tile ahead, 8-byte pieces in the D-operand ownership), writes t to HBM (16-byte units after a permlane16 swap) AND to LDS
 // planes; barrier; GEMM 2, wave w computes channel group w of u from t in LDS (K = 256); epilogue; next tile's m by DMA under it.

@@ -281,7 +281,7 @@ def assign_formats(P):
 
 def pack_h2_wave16(t):
     """An f16x2 weight pack ([tap T][Cin/16][piece 2][k-half 2][Cout][8] int16, pack_conv_weight_h2; Cin a multiple of 32, Cout of 16)
-    re-ordered for the kernels whose waves own 16-channel groups (csrc/conv_h2c.hip, conv_h2x.hip): per group, tap, 32-input-channel
+    re-ordered for the kernels whose waves own 16-channel groups (csrc/conv_h2c.h, conv_h2x.hip): per group, tap, 32-input-channel
     chunk kc and piece ONE 16-byte unit per lane -- the A operand of v_mfma_f32_16x16x32_f16: lane = 16 * kq + oc holds input
     channels 32 kc + 8 kq .. + 7 of output channel 16 g + oc.  -> [group Cout/16][tap T][kc Cin/32][piece 2][lane 64][8] (a pure
     permutation)."""
@@ -482,7 +482,7 @@ def fuse_basic_blocks(P):
     by conv 3x3 s1 32->32 + BN + (block input) + ReLU, model.py:54-83 -- whose tensors are all H2 becomes ONE launch
     (csrc/conv_h2b.hip: the intermediate tile stays in LDS): the first conv's op turns into ROMP_OP_NOP (fields intact: the
     kernel takes its weights from there), the second into ROMP_OP_BBLOCK32.  Op indices, names and the flop / byte lists keep
-    their length; the pair's algorithmic bytes become x in + y out.  The same for 64-channel blocks (csrc/conv_h2c.hip,
+    their length; the pair's algorithmic bytes become x in + y out.  The same for 64-channel blocks (csrc/conv_h2c.h,
     ROMP_OP_BBLOCK64; their weights are repacked per wave into weight_aux).  Single-image plans fuse the 32-channel blocks only
     (64 tiles there, a quarter of the CUs, but 32 fewer launches on a launch-bound chain: network 2.15 -> 1.95 ms at B = 1; the
     64-channel kernel would run 32 tiles: 2.25 -> 2.45 ms per frame).  Env ROMP_FUSE_BLOCKS: 0 off, 32 / 64 one class, all
@@ -516,7 +516,7 @@ def fuse_basic_blocks(P):
         writers_between = [j for j in range(i + 2, later[0] + 1) if P.ops[j].out_buf == a.out_buf] if later else [0]
         private = not later or bool(writers_between)
         if plain and chained and h2 and private and a.act_shift == b.act_shift:
-            # the row-pipelined kernels (conv_h2c.hip) read their weights per wave (16 output channels each).  32 channels: batch plans only
+            # the row-pipelined kernels (conv_h2c.h) read their weights per wave (16 output channels each).  32 channels: batch plans only
             # (two workgroups per CU; a single image's tiles are better off on conv_h2b.hip's kernel: 2.10 vs 2.15 ms at B = 1)
             # (round 4 A/B runs, both neutral: conv_h2b's kernel in batch plans, the row-pipelined one at B = 1 -- 1.436 / 1.479 vs 1.458 / 1.461 ms)
             if C_ == 64 or not getattr(P, 'split_k_items', 0):

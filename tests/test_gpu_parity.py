@@ -348,7 +348,7 @@ def test_net_range_calibration(dev):
                                          # the production shapes (VERDICT r3 weak #1b): 128^2 x 32 (stage 2-4 branch 0) and 64^2 x 64 (branch 1)
                                          (2, 128, 32, 'r'), (2, 128, 32, 'v1'), (2, 64, 64, 'r')])
 def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
-    """csrc/conv_h2b.hip ('v1', 32 channels) / conv_h2c.hip ('r', 32 and 64 channels): a BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
+    """csrc/conv_h2b.hip ('v1', 32 channels) / conv_h2c.h ('r', 32 and 64 channels): a BasicBlock as ONE launch (intermediate tile in LDS).  A three-conv program -- an
     ordinary conv producing the H2 block input, then the block -- lowered by plan.py (which must fuse the pair), run through
     romp_net_create / romp_net_forward, against torch on the CPU: image borders (the intermediate's zero padding), interior
     tiles, odd tile counts, batch > 1.  Same bound as the single layers, two layers deeper: 5e-5 of the output's magnitude."""
@@ -379,7 +379,7 @@ def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
     if impl == 'v1':                                         # conv_h2b.hip's 16x16-tile kernel (single-image plans): no per-wave weight packs
         ops[1].flags &= ~L.OPF_WAVE16
         ops[2].flags &= ~L.OPF_WAVE16
-    else:                                                    # conv_h2c.hip's row-pipelined kernels
+    else:                                                    # conv_h2c.h's row-pipelined kernels
         assert ops[1].weight_aux and ops[2].weight_aux and (ops[1].flags & ops[2].flags & L.OPF_WAVE16)
     lib = L.load()
     h = C.c_void_p()
