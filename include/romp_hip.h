@@ -87,7 +87,7 @@ const char* romp_last_error(void);
 #define ROMP_OP_SEAM1X1   15    /* two 1x1 convs across a Bottleneck seam of layer1 as one kernel (csrc/conv_h2x.hip,
                                    plan.fuse_bottleneck_seams): the op before it (NOP) is a
                                    64->256 conv + residual + ReLU, this op the 256->64 conv + ReLU reading its output; both
-                                   outputs are written; weight_aux = per-group packs                                            */
+                                   outputs are written; weight_aux = per-group packs.  With ROMP_OPF_SEAM_DS: see the flag     */
 #define ROMP_OP_FUSEUP    16    /* a fuse-layer output with its 1x1 up-convs inside (csrc/conv_fup.hip, plan.fuse_up_sums; model.py:186-196,233-244):
                                    y = relu(sum of the terms), terms in op order: first the tensors already at the output's resolution
                                    (term_shift 0), then for term_shift s = 1, 2, ..: nearest_up_2^s(bn(W_s . x_s)) where term_buf is the
@@ -106,6 +106,10 @@ const char* romp_last_error(void);
 #define ROMP_OPF_WAVE16     1   /* weight_aux holds the f16x2 weights repacked per wave for 16-channel MFMA rows
                                    (plan.pack_h2_wave16: BBLOCK64, SEAM1X1 and the row-pipelined BBLOCK32 kernel), not a
                                    bf16x3 pack: the fused kernels dispatch on this bit, never on weight_aux != NULL   */
+#define ROMP_OPF_SEAM_DS    4   /* SEAM1X1 behind Bottleneck 0 (model.py:289-301): the residual of the 64->256 conv is itself a conv,
+                                   bn_d(conv1x1 64->256(x0)) -- the `downsample` branch -- and the seam kernel computes it too: the
+                                   op TWO before this one (NOP, fields intact) is that conv, its in_buf x0 the kernel's third input;
+                                   its 256-channel output tensor is never written                                        */
 #define ROMP_OPF_STEM_VALU  2   /* STEM: take the float32 VALU kernel even for an H2 output (A/B runs, tests; also chosen
                                    when 256 * |w| does not fit the fp16 pieces of the MFMA form)                      */
 

@@ -37,6 +37,8 @@ struct ConvParams {
     unsigned long long* trace;   // nullptr, or TRACE_SLOTS words per wave: (s_memtime << 8 | event code) stamps (env ROMP_CONV_TRACE=1;
                                  // split-precision kernels only; read back with romp_conv_trace_read, scripts/conv_trace.py)
     float* out2; int out2_cs, out2_co;   // (conv_h2x.hip) the second output tensor
+    const uint4* wx; const float* scale_x; const float* shift_x;   // (conv_h2x.hip, DS) the folded downsample conv: weights, f16x2 scale, shift
+    unsigned res_bytes;       // (conv_h2x.hip, DS) bytes of the tensor at res + res_co (the downsample's input): num_records of its raw buffer
     unsigned in_bytes;        // (fused block kernel) bytes of the input tensor from in + in_co on: num_records of its raw buffer
     int relu_from;            // relu != 0: ReLU on output channels >= relu_from only (romp_op.relu_from; a multiple of 32)
     int* sat;                 // saturation counter of the running net (conv_sat_counter(), may be nullptr): +1 per wave and work item that

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -296,7 +296,14 @@ def fuse_bottleneck_seams(P):
     residual + ReLU, model.py:103-123) and the first conv of the next one (1x1 256 -> 64 + ReLU) as one launch that writes the
     256-channel tensor (the next block's residual) but does not read it back: 1.87 -> 1.34 GB per seam at B = 32, 2 709 -> 2 802
     images/s.  Batch plans (single-image plans: no measurable difference, 2.22-2.48 vs 2.33-2.35 ms per frame); env ROMP_FUSE_SEAMS=0
-    switches it off, =all also fuses in single-image plans (A/B runs).  -> number of fused seams."""
+    switches it off, =all also fuses in single-image plans (A/B runs).  -> number of fused seams.
+
+    Round 5 (OPF_SEAM_DS): behind Bottleneck 0 the residual is the output of the block's `downsample` conv (1x1 64 -> 256 + BN on the
+    block input x0, model.py:289-301), the op right before the seam's first conv.  The seam kernel computes it as a second product
+    from an x0 tile instead of loading it: that conv turns into a NOP as well (fields intact, two ops before the SEAM1X1), its
+    256-channel output is never written or read (2 x 537 MB and one launch less at B = 32).  Only when nothing else reads that
+    output and x0's buffer is still intact when the seam runs (build_hrnet32_backbone frees it one conv late for this);
+    env ROMP_SEAM_DS=0 keeps the downsample a launch of its own (A/B runs)."""
     import os
     P.fused_seams = 0
     if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_SEAMS', '1') not in ('1', 'all') or (getattr(P, 'split_k_items', 0) and os.environ.get('ROMP_FUSE_SEAMS', '1') != 'all'):
@@ -328,6 +335,34 @@ def fuse_bottleneck_seams(P):
         P.bytes[i + 1] = 4.0 * a.H * a.W * (64 + 256 + 256 + 64)
         P.bytes[i] = 0.0
         P.fused_seams += 1
+        d = P.ops[i - 1] if i >= 1 else None
+        if d is None or os.environ.get('ROMP_SEAM_DS', '1') == '0':
+            continue
+        fold = (d.kind == OP_CONV and d.ksize == 1 and d.stride == 1 and d.groups == 1 and d.Cin == 64 and d.Cout == 256 and d.cin_pad == 64 and
+                d.cout_pad == 256 and not d.relu and d.res_buf < 0 and d.weight_h2 and d.scale_h2 and d.out_buf == a.res_buf and
+                (d.out_cstride, d.out_coff) == (a.res_cstride, a.res_coff) and d.out_rstride == 0 and d.out_bstride == 0 and
+                d.stream == a.stream and (d.H, d.W) == (a.H, a.W) and d.in_fmt == FMT_H2 and d.out_fmt == FMT_H2 and
+                d.act_shift == a.act_shift and d.in_cstride % 8 == 0 and d.in_coff % 8 == 0 and
+                d.in_buf >= 0 and d.in_buf not in (a.out_buf, b.out_buf))           # x0 must still be there when the seam runs
+        for j in range(i + 1, len(P.ops)):                       # nobody else reads the downsample's output (until the buffer's next writer)
+            o = P.ops[j]
+            if not fold or (o.out_buf == d.out_buf and o.kind not in (OP_NOP, OP_FORK, OP_JOIN, OP_RECORD, OP_WAIT)):
+                break
+            if d.out_buf in [o.in_buf, o.res_buf] + [o.term_buf[k] for k in range(o.n_terms)]:
+                fold = False
+        if not fold:
+            continue
+        t = pack_h2_wave16(by_ptr[d.weight_h2].view(1, 4, 2, 2, 256, 8))
+        P.consts.append(t)
+        d.weight_aux = t.data_ptr()
+        d.flags |= OPF_WAVE16
+        d.kind = OP_NOP
+        b.flags |= OPF_SEAM_DS
+        P.flops[i + 1] += P.flops[i - 1]
+        P.flops[i - 1] = 0.0
+        P.bytes[i + 1] = 4.0 * a.H * a.W * (64 + 64 + 256 + 64)
+        P.bytes[i - 1] = 0.0
+        P.folded_downsamples = getattr(P, 'folded_downsamples', 0) + 1
     return P.fused_seams
 
 
@@ -450,8 +485,11 @@ def stream_races(P):
     def touched(i):
         op, r, w = ops[i], [], []
         srcs = [op] + ([ops[i - 1]] if op.kind in (OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1) else [])    # a fused pair: the NOP before it holds the first conv
+        seam_ds = op.kind == OP_SEAM1X1 and (op.flags & OPF_SEAM_DS)
+        if seam_ds:                                              # the folded downsample: its input is read, its output never materialises
+            r.append(ops[i - 2].in_buf)
         for o in srcs:
-            r += [b for b in (o.in_buf, o.res_buf) if b >= 0]
+            r += [b for b in ((o.in_buf,) if (seam_ds and o is not op) else (o.in_buf, o.res_buf)) if b >= 0]
             if o.kind in (OP_FUSESUM, OP_FUSEUP):
                 r += [o.term_buf[k] for k in range(o.n_terms) if o.term_buf[k] >= 0]
             w += [b for b in [o.out_buf] + ([o.term_buf[0]] if o.kind == OP_BEV_MAPS else []) if b >= 0]
@@ -858,14 +896,18 @@ def build_hrnet32_backbone(P: Program, sd, input_size=512, out_cstride=32) -> Ac
     P.free(x)
     x = y
     # ---- layer1: 4 Bottlenecks (model.py:103-123, :345)
+    late_free = None
     for i in range(4):
         p = f'{bb}layer1.{i}.'
         t1 = cbr(p + 'conv1', x, p + 'conv1', p + 'bn1', 1, 1, True)
+        if late_free is not None:                                # the stem output: when the downsample conv is folded into the seam kernel
+            P.free(late_free)                                    # (fuse_bottleneck_seams, OPF_SEAM_DS) that launch -- THIS conv's -- still reads it
+            late_free = None
         t2 = cbr(p + 'conv2', t1, p + 'conv2', p + 'bn2', 3, 1, True)
         P.free(t1)
         if (p + 'downsample.0.weight') in sd:
             r = cbr(p + 'downsample', x, p + 'downsample.0', p + 'downsample.1', 1, 1, False)
-            P.free(x)
+            late_free = x
         else:
             r = x
         y = cbr(p + 'conv3', t2, p + 'conv3', p + 'bn3', 1, 1, True, res=r)

@@ -1207,3 +1207,74 @@ def test_seam1x1(dev, B, H, monkeypatch):
             assert err < 5e-5, (name, err)
     finally:
         lib.romp_net_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H', [(1, 16), (3, 32), (2, 128)])
+def test_seam1x1_downsample(dev, B, H, monkeypatch):
+    """csrc/conv_h2x.hip, DS = 1 (round 5, OPF_SEAM_DS): the seam behind Bottleneck 0 -- t = relu(bn3(conv1x1(m)) + bn_d(conv1x1(x0))),
+    the residual being the block's own `downsample` conv of the block input (model.py:289-301) -- as one launch that never
+    materialises the downsample output; both outputs against torch on the CPU, and against the ROMP_SEAM_DS=0 lowering of the
+    same program (the downsample as a launch of its own)."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math, decode_h2
+    monkeypatch.setenv('ROMP_FUSE_SEAMS', '1')
+    g = torch.Generator().manual_seed(11 * B + H)
+    img = torch.randn(B, H, H, 64, generator=g)
+    dims = [(64, 64), (64, 64), (64, 256), (64, 256), (256, 64), (64, 64)]      # x0, m, downsample, conv3, next conv1, a reader of u
+    ws = [torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5 for ci, co in dims]
+    sc = [torch.rand(co, generator=g) + 0.5 for _, co in dims]
+    sh = [torch.randn(co, generator=g) * 0.2 for _, co in dims]
+
+    def cb(t, i, relu=True, res=None):
+        y = F.conv2d(t, ws[i], None) * sc[i].view(1, -1, 1, 1) + sh[i].view(1, -1, 1, 1)
+        y = y if res is None else y + res
+        return torch.relu(y) if relu else y
+    r0 = cb(img.permute(0, 3, 1, 2), 0)
+    rm = cb(r0, 1)
+    rd = cb(r0, 2, relu=False)
+    rt = cb(rm, 3, res=rd)
+    ru = cb(rt, 4)
+    outs = {}
+    for ds in ('1', '0'):
+        monkeypatch.setenv('ROMP_SEAM_DS', ds)
+        P = Program(dev)
+        set_conv_math(P, 'f16x2')
+        a0 = P.conv('x0', Act(L.BUF_IMAGE, 64, H, H, 64), [ws[0]], [sc[0]], [sh[0]], 1, 1, True)
+        am = P.conv('m', a0, [ws[1]], [sc[1]], [sh[1]], 1, 1, True)
+        ad = P.conv('d', a0, [ws[2]], [sc[2]], [sh[2]], 1, 1, False)
+        at = P.conv('t', am, [ws[3]], [sc[3]], [sh[3]], 1, 1, True, res=ad)
+        au = P.conv('u', at, [ws[4]], [sc[4]], [sh[4]], 1, 1, True)
+        av = P.conv('v', au, [ws[5]], [sc[5]], [sh[5]], 1, 1, True)
+        ops = P.op_array()
+        kinds = [o.kind for o in P.ops]
+        if ds == '1':
+            assert P.fused_seams == 1 and P.folded_downsamples == 1 and kinds == [L.OP_CONV, L.OP_CONV, L.OP_NOP, L.OP_NOP, L.OP_SEAM1X1, L.OP_CONV], kinds
+            assert P.ops[4].flags & L.OPF_SEAM_DS
+        else:
+            assert P.fused_seams == 1 and kinds == [L.OP_CONV, L.OP_CONV, L.OP_CONV, L.OP_NOP, L.OP_SEAM1X1, L.OP_CONV], kinds
+        lib = L.load()
+        h = C.c_void_p()
+        sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+        L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+        try:
+            xd = img.to(dev).contiguous()
+            dummy = torch.empty(16, device=dev)
+            L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+            for act, ref, name in ((at, rt, 't'), (au, ru, 'u')):
+                n = P.buf_floats[act.buf] * B
+                out = torch.empty(n, device=dev)
+                L.check(lib.romp_net_read_buffer(h, act.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
+                torch.cuda.synchronize()
+                y = decode_h2(out.cpu().reshape(B, H, H, act.C))
+                r = ref.permute(0, 2, 3, 1)
+                err = (y - r).abs().max().item() / r.abs().max().item()
+                print(f'seam1x1 ds={ds} B={B} {H}x{H} {name}: relative err {err:.3e}')
+                assert err < 5e-5, (ds, name, err)
+                outs[(ds, name)] = y
+        finally:
+            lib.romp_net_destroy(h)
+    for name in ('t', 'u'):                                      # the two lowerings agree to float32 rounding (the fold adds in float32 what
+        d = (outs[('1', name)] - outs[('0', name)]).abs().max().item()      # the separate launch rounds to two fp16 pieces first)
+        assert d < 2e-5 * max(1.0, outs[('0', name)].abs().max().item()), (name, d)
