@@ -444,8 +444,21 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #pragma unroll
             for (int r = 0; r < X::THW; ++r) asm volatile("" :: "v"(acc2[r]));
         }
-        // ---- 4. the next halo has landed, for every wave; m may be overwritten
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // ---- 4. the next halo has landed, for every wave; m may be overwritten.  A COUNTED wait (round 5): the halo pieces go out under
+        // the first FR m rows, each output row's store at the end of its row from row 3 on, so exactly MRW2 - max(3, FR - 1) stores are
+        // younger than the last piece; a wave's memory operations retire in issue order: "at most that many outstanding" = every piece
+        // has landed while the tile's last stores stay in flight across the barrier (vmcnt(0) waited one store round trip per tile
+        // with nothing to compute).  Knock-out builds without the finish have no stores to count on: full drain
+        constexpr int FRW = (X::MRW2 + 1) / 2;                  // (= FR of the conv2 loop above)
+        constexpr int STORES_AFTER_DMA = X::MRW2 - (FRW - 1 > 3 ? FRW - 1 : 3);
+        static_assert(STORES_AFTER_DMA == (C == 64 ? 6 : 3), "the counted wait below");
+#ifdef ROMP_BBLOCK_DRAIN0                                      // (A/B builds: the full drain of rounds 3-4; python -m romp_amd.build with extra_flags)
+        if (true) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+        if (DBG & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+        else if (C == 64) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ROMP_TRACE(15);
         itp = it;
