@@ -110,8 +110,6 @@ const char* romp_last_error(void);
                                    bn_d(conv1x1 64->256(x0)) -- the `downsample` branch -- and the seam kernel computes it too: the
                                    op TWO before this one (NOP, fields intact) is that conv, its in_buf x0 the kernel's third input;
                                    its 256-channel output tensor is never written                                        */
-#define ROMP_OPF_SEAM_TAIL  8   /* SEAM1X1 in its tail form: the last Bottleneck of layer1 (its 64->256 conv + residual + ReLU, nothing behind
-                                   it to fuse with): this op IS that conv (no NOP before it), one output                  */
 #define ROMP_OPF_STEM_VALU  2   /* STEM: take the float32 VALU kernel even for an H2 output (A/B runs, tests; also chosen
                                    when 256 * |w| does not fit the fp16 pieces of the MFMA form)                      */
 

@@ -48,7 +48,7 @@ void conv_set_wg_cap(int cap);                                 // fused kernels:
 int conv_wg_cap();
 bool conv_sat_checked();                                       // fused-block kernels: launch the builds that count too
 unsigned long long* conv_trace_arm(hipStream_t st);   // conv_mfma.hip: ROMP_CONV_TRACE stamp buffer, zeroed on `st` (nullptr: off)
-int launch_seam1x1(const romp_op& opa, const romp_op* opb, const romp_op* opd, const float* m, const float* x, float* t, float* u, int B, hipStream_t st);   // conv_h2x.hip
+int launch_seam1x1(const romp_op& opa, const romp_op& opb, const romp_op* opd, const float* m, const float* x, float* t, float* u, int B, hipStream_t st);   // conv_h2x.hip
 int launch_bblock32r(const romp_op& op1, const romp_op& op2, const float* x, float* y, int B, int* queue, hipStream_t st);  // conv_h2c.hip
 int launch_bblock64(const romp_op& op1, const romp_op& op2, const float* x, float* y, int B, int* queue, hipStream_t st);   // conv_h2c.hip
 int launch_bblock32(const romp_op& op1, const romp_op& op2, const float* x, float* y, int B, int* queue, hipStream_t st);

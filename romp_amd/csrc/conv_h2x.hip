@@ -38,13 +38,13 @@ struct XCfg {
     static constexpr int OFF_M1 = OFF_T + TPLN * N * 16;       // 81 920: the second m buffer
     static constexpr int OFF_X = OFF_M1 + MBYTES;              // 98 304: (DS) the two x0 buffers
     static constexpr int lds_bytes(int ds) { return ds ? OFF_X + 2 * MBYTES : OFF_X; }   // 98 304 / 131 072
-    // memory operations a wave issues per tile AFTER the tile DMAs: 16 t stores, (32 residual loads,) (4 u stores)
-    static constexpr int after_dma(int ds, int u) { return 16 + (ds ? 0 : 32) + (u ? 4 : 0); }
+    // memory operations a wave issues per tile AFTER the tile DMAs: 16 t stores, (32 residual loads,) 4 u stores
+    static constexpr int after_dma(int ds) { return ds ? 16 + 4 : 16 + 32 + 4; }
 };
 
 typedef float f32x4x __attribute__((ext_vector_type(4)));
 
-template <int DS, int U = 1>
+template <int DS>
 __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
     using X = XCfg;
     using frag = f16x8;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
     if (k0 >= n_tiles) return;
 
     // ---- weights: GEMM 1 groups 4 wv + gi (K = 64: 2 chunks; DS: the downsample conv's too), GEMM 2 group wv (K = 256: 8 chunks)
-    frag w3[4][2][2], wd[DS ? 4 : 1][2][2], w1[U ? 8 : 1][2];
+    frag w3[4][2][2], wd[DS ? 4 : 1][2][2], w1[8][2];
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi)
 #pragma unroll
@@ -69,12 +69,10 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
                 w3[gi][kc][pc] = __builtin_bit_cast(frag, p.w3[(((4 * wv + gi) * 2 + kc) * 2 + pc) * 64 + lane]);
                 if (DS) wd[gi][kc][pc] = __builtin_bit_cast(frag, p.wx[(((4 * wv + gi) * 2 + kc) * 2 + pc) * 64 + lane]);
             }
-    if constexpr (U) {
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc)
+    for (int kc = 0; kc < 8; ++kc)
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) w1[kc][pc] = __builtin_bit_cast(frag, p.wh[((wv * 8 + kc) * 2 + pc) * 64 + lane]);
-    }
+        for (int pc = 0; pc < 2; ++pc) w1[kc][pc] = __builtin_bit_cast(frag, p.wh[((wv * 8 + kc) * 2 + pc) * 64 + lane]);
     // scale / shift of this lane's channels, pre-multiplied by 2^act_shift (DS: b3 = bn3's shift + bn_d's)
     f32x4x s3[4], b3[4], sd[DS ? 4 : 1], s1, b1;
 #pragma unroll
@@ -85,12 +83,10 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
             s3[gi][i] = p.scale[c] * p.act_scale; b3[gi][i] = p.w[c] * p.act_scale;
             if (DS) { sd[gi][i] = p.scale_x[c] * p.act_scale; b3[gi][i] = (p.w[c] + p.shift_x[c]) * p.act_scale; }
         }
-    if constexpr (U) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = 16 * wv + 4 * q + i;
-            s1[i] = p.scale_h[c] * p.act_scale; b1[i] = p.shift[c] * p.act_scale;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int c = 16 * wv + 4 * q + i;
+        s1[i] = p.scale_h[c] * p.act_scale; b1[i] = p.shift[c] * p.act_scale;
     }
 
     // ---- m (and x0) tile by DMA: plane pl = 4 k + wv (k < 4) is this wave's k-th piece; lane = pixel
@@ -152,10 +148,8 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
             asm volatile("" : "+v"(w3[gi][kc][0]), "+v"(w3[gi][kc][1]));
             if (DS) asm volatile("" : "+v"(wd[gi][kc][0]), "+v"(wd[gi][kc][1]));
         }
-    if constexpr (U) {
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) asm volatile("" : "+v"(w1[kc][0]), "+v"(w1[kc][1]));
-    }
+    for (int kc = 0; kc < 8; ++kc) asm volatile("" : "+v"(w1[kc][0]), "+v"(w1[kc][1]));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -218,80 +212,70 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
                 sat_track(sat_mx, v[2], v[3]);
                 unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
                 unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
-                if constexpr (U) {
-                    char* tl = sBuf + X::OFF_T + ((2 * (2 * g + (q >> 1))) * X::N + 16 * pb + px) * 16 + (q & 1) * 8;
-                    *reinterpret_cast<uint2*>(tl) = make_uint2(hh[0], hh[1]);
-                    *reinterpret_cast<uint2*>(tl + X::N * 16) = make_uint2(hl[0], hl[1]);
-                }
+                char* tl = sBuf + X::OFF_T + ((2 * (2 * g + (q >> 1))) * X::N + 16 * pb + px) * 16 + (q & 1) * 8;
+                *reinterpret_cast<uint2*>(tl) = make_uint2(hh[0], hh[1]);
+                *reinterpret_cast<uint2*>(tl + X::N * 16) = make_uint2(hl[0], hl[1]);
                 const u32x2_t a = __builtin_amdgcn_permlane16_swap(hh[0], hl[0], false, false);
                 const u32x2_t b = __builtin_amdgcn_permlane16_swap(hh[1], hl[1], false, false);
                 *reinterpret_cast<uint4*>(tout + (size_t)(16 * pb) * p.out_cs + 16 * g) = make_uint4(a[0], b[0], a[1], b[1]);
             }
         if constexpr (!DS) { if (has_next) load_res(nxt, res); }               // the next tile's residual: a GEMM 2 + a GEMM 1 to arrive
-        if constexpr (U) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                          // t is complete
-            // ---- GEMM 2: u group wv from t (K = 256)
-            f32x4x acc2[4];
-    #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) acc2[pb] = (f32x4x){0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
-            for (int kc = 0; kc < 8; ++kc)
-    #pragma unroll
-                for (int pb = 0; pb < 4; ++pb) {
-                    frag x[2];
-    #pragma unroll
-                    for (int pc = 0; pc < 2; ++pc) x[pc] = *reinterpret_cast<const frag*>(sBuf + ta + ((8 * kc + pc) * X::N + 16 * pb) * 16);
-                    acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[kc][1], x[0], acc2[pb], 0, 0, 0);
-                    acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[kc][0], x[1], acc2[pb], 0, 0, 0);
-                    acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[kc][0], x[0], acc2[pb], 0, 0, 0);
-                }
-            float* uout = p.out2 + (size_t)(tile * X::N + px) * p.out2_cs + p.out2_co + 16 * wv + 4 * q;
-    #pragma unroll
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // t is complete
+        // ---- GEMM 2: u group wv from t (K = 256)
+        f32x4x acc2[4];
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) acc2[pb] = (f32x4x){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
-                float v[4];
-    #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = h2_sat(fmaxf(fmaf(acc2[pb][e], s1[e], b1[e]), 0.f));
-                sat_track(sat_mx, v[0], v[1]);
-                sat_track(sat_mx, v[2], v[3]);
-                unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
-                unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
-                const u32x2_t a = __builtin_amdgcn_permlane16_swap(hh[0], hl[0], false, false);
-                const u32x2_t b = __builtin_amdgcn_permlane16_swap(hh[1], hl[1], false, false);
-                *reinterpret_cast<uint4*>(uout + (size_t)(16 * pb) * p.out2_cs) = make_uint4(a[0], b[0], a[1], b[1]);
+                frag x[2];
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) x[pc] = *reinterpret_cast<const frag*>(sBuf + ta + ((8 * kc + pc) * X::N + 16 * pb) * 16);
+                acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[kc][1], x[0], acc2[pb], 0, 0, 0);
+                acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[kc][0], x[1], acc2[pb], 0, 0, 0);
+                acc2[pb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[kc][0], x[0], acc2[pb], 0, 0, 0);
             }
+        float* uout = p.out2 + (size_t)(tile * X::N + px) * p.out2_cs + p.out2_co + 16 * wv + 4 * q;
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h2_sat(fmaxf(fmaf(acc2[pb][e], s1[e], b1[e]), 0.f));
+            sat_track(sat_mx, v[0], v[1]);
+            sat_track(sat_mx, v[2], v[3]);
+            unsigned hh[2] = {pack_hi(v[0], v[1]), pack_hi(v[2], v[3])};
+            unsigned hl[2] = {h2_low_pair(hh[0], v[0], v[1]), h2_low_pair(hh[1], v[2], v[3])};
+            const u32x2_t a = __builtin_amdgcn_permlane16_swap(hh[0], hl[0], false, false);
+            const u32x2_t b = __builtin_amdgcn_permlane16_swap(hh[1], hl[1], false, false);
+            *reinterpret_cast<uint4*>(uout + (size_t)(16 * pb) * p.out2_cs) = make_uint4(a[0], b[0], a[1], b[1]);
         }
         // ---- the next m (x0) has landed (see the header): everything older than the operations issued after the DMAs has completed.
         // Barrier: every wave's share of it is there, t may be overwritten
-        static_assert(X::after_dma(0, 1) == 52 && X::after_dma(1, 1) == 20 && X::after_dma(0, 0) == 48, "the counted waits below");
+        static_assert(X::after_dma(0) == 52 && X::after_dma(1) == 20, "the counted waits below");
         if (DS) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-        else if (U) asm volatile("s_waitcnt vmcnt(52) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(48) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(52) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mb ^= 1;
     }
     sat_report(p.sat, sat_mx);
 }
 
-// `opa`: the 64 -> 256 conv (+ residual + ReLU), `opb`: the 256 -> 64 conv (+ ReLU) reading its output -- or nullptr: the LAST
-// Bottleneck of the layer (ROMP_OPF_SEAM_TAIL on opa: t only, no second conv, `u` unused).  `opd` (or nullptr): the 64 -> 256
-// downsample conv whose output WAS opa's residual (ROMP_OPF_SEAM_DS on opb; plan.fuse_bottleneck_seams); `x` is then opd's INPUT
-// tensor (64 channels)
-int launch_seam1x1(const romp_op& opa, const romp_op* opb, const romp_op* opd, const float* m, const float* x, float* t, float* u, int B, hipStream_t st) {
-    ROMP_REQUIRE(opa.ksize == 1 && opa.stride == 1 && opa.Cin == 64 && opa.Cout == 256 && opa.groups == 1 && opa.relu && opa.res_buf >= 0,
-                 "seam1x1: a 1x1 64 -> 256 conv + residual + ReLU expected");
-    ROMP_REQUIRE(opa.weight_aux && opa.scale_h2 && (opa.flags & ROMP_OPF_WAVE16), "seam1x1: per-group f16x2 weight packs (ROMP_OPF_WAVE16) expected");
-    ROMP_REQUIRE(opa.in_fmt == ROMP_FMT_H2 && opa.res_fmt == ROMP_FMT_H2 && opa.out_fmt == ROMP_FMT_H2, "seam1x1: H2 tensors expected");
-    ROMP_REQUIRE(((long)B * opa.H * opa.W) % XCfg::N == 0, "seam1x1: pixel count not a multiple of 64");
-    ROMP_REQUIRE(((opa.in_cstride | opa.in_coff | opa.res_cstride | opa.res_coff | opa.out_cstride | opa.out_coff) & 7) == 0 &&
-                 opa.out_rstride == 0 && opa.out_bstride == 0, "seam1x1: dense, octet-aligned tensors expected");
-    if (opb)
-        ROMP_REQUIRE(opb->ksize == 1 && opb->stride == 1 && opb->Cin == 256 && opb->Cout == 64 && opb->groups == 1 && opb->relu &&
-                     opb->weight_aux && opb->scale_h2 && (opb->flags & ROMP_OPF_WAVE16) && opb->in_fmt == ROMP_FMT_H2 && opb->out_fmt == ROMP_FMT_H2 &&
-                     opa.act_shift == opb->act_shift && opa.H == opb->H && opa.W == opb->W && ((opb->out_cstride | opb->out_coff) & 7) == 0 &&
-                     opb->out_rstride == 0 && opb->out_bstride == 0,
-                     "seam1x1: the second conv must be a 1x1 256 -> 64 conv + ReLU on H2 tensors, dense and octet aligned, with a per-group pack");
-    ROMP_REQUIRE(opb || !opd, "seam1x1: no downsample fold in the tail form");
+// `opa`: the 64 -> 256 conv (+ residual + ReLU), `opb`: the 256 -> 64 conv (+ ReLU) reading its output.  `opd` (or nullptr): the
+// 64 -> 256 downsample conv whose output WAS opa's residual (ROMP_OPF_SEAM_DS on opb; plan.fuse_bottleneck_seams); `x` is then
+// opd's INPUT tensor (64 channels)
+int launch_seam1x1(const romp_op& opa, const romp_op& opb, const romp_op* opd, const float* m, const float* x, float* t, float* u, int B, hipStream_t st) {
+    ROMP_REQUIRE(opa.ksize == 1 && opa.stride == 1 && opa.Cin == 64 && opa.Cout == 256 && opa.groups == 1 && opa.relu &&
+                 opb.ksize == 1 && opb.stride == 1 && opb.Cin == 256 && opb.Cout == 64 && opb.groups == 1 && opb.relu,
+                 "seam1x1: a 1x1 64 -> 256 conv + residual + ReLU followed by a 1x1 256 -> 64 conv + ReLU expected");
+    ROMP_REQUIRE(opa.weight_aux && opa.scale_h2 && opb.weight_aux && opb.scale_h2 && (opa.flags & opb.flags & ROMP_OPF_WAVE16),
+                 "seam1x1: per-group f16x2 weight packs (ROMP_OPF_WAVE16) expected");
+    ROMP_REQUIRE(opa.in_fmt == ROMP_FMT_H2 && opa.res_fmt == ROMP_FMT_H2 && opa.out_fmt == ROMP_FMT_H2 && opb.in_fmt == ROMP_FMT_H2 &&
+                 opb.out_fmt == ROMP_FMT_H2 && opa.act_shift == opb.act_shift, "seam1x1: H2 tensors expected");
+    ROMP_REQUIRE(((long)B * opa.H * opa.W) % XCfg::N == 0 && opa.H == opb.H && opa.W == opb.W, "seam1x1: pixel count not a multiple of 64");
+    ROMP_REQUIRE(((opa.in_cstride | opa.in_coff | opa.res_cstride | opa.res_coff | opa.out_cstride | opa.out_coff | opb.out_cstride | opb.out_coff) & 7) == 0 &&
+                 opa.out_rstride == 0 && opa.out_bstride == 0 && opb.out_rstride == 0 && opb.out_bstride == 0, "seam1x1: dense, octet-aligned tensors expected");
     if (opd)
         ROMP_REQUIRE(opd->ksize == 1 && opd->stride == 1 && opd->Cin == 64 && opd->Cout == 256 && opd->groups == 1 && !opd->relu && opd->res_buf < 0 &&
                      opd->weight_aux && opd->scale_h2 && (opd->flags & ROMP_OPF_WAVE16) && opd->in_fmt == ROMP_FMT_H2 && opd->act_shift == opa.act_shift &&
@@ -302,7 +286,6 @@ int launch_seam1x1(const romp_op& opa, const romp_op* opb, const romp_op* opd, c
     if (!attr) {
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(0)));
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(1)));
-        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(0)));
         int dev = 0;
         hipDeviceProp_t prop;
         ROMP_HIP_CHECK(hipGetDevice(&dev));
@@ -315,12 +298,9 @@ int launch_seam1x1(const romp_op& opa, const romp_op* opb, const romp_op* opd, c
     memset(&p, 0, sizeof(p));
     p.in = m; p.res = x; p.out = t; p.out2 = u;
     p.w3 = reinterpret_cast<const uint4*>(opa.weight_aux);
+    p.wh = reinterpret_cast<const uint4*>(opb.weight_aux);
     p.scale = opa.scale_h2; p.w = opa.shift;
-    if (opb) {
-        p.wh = reinterpret_cast<const uint4*>(opb->weight_aux);
-        p.scale_h = opb->scale_h2; p.shift = opb->shift;
-        p.out2_cs = opb->out_cstride; p.out2_co = opb->out_coff;
-    }
+    p.scale_h = opb.scale_h2; p.shift = opb.shift;
     p.act_scale = ldexpf(1.f, opa.act_shift);
     p.sat = conv_sat_counter();
     {
@@ -339,11 +319,11 @@ int launch_seam1x1(const romp_op& opa, const romp_op* opb, const romp_op* opd, c
         p.res_bytes = (unsigned)bytes;
     }
     p.out_cs = opa.out_cstride; p.out_co = opa.out_coff;
+    p.out2_cs = opb.out_cstride; p.out2_co = opb.out_coff;
     p.tiles_total = (int)(((long)B * opa.H * opa.W) / XCfg::N);
     long grid = num_cu;
     if (grid > p.tiles_total) grid = p.tiles_total;
-    if (!opb) hipLaunchKernelGGL((seam1x1_kernel<0, 0>), dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(0), st, p);
-    else if (opd) hipLaunchKernelGGL(seam1x1_kernel<1>, dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(1), st, p);
+    if (opd) hipLaunchKernelGGL(seam1x1_kernel<1>, dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(1), st, p);
     else hipLaunchKernelGGL(seam1x1_kernel<0>, dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(0), st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;

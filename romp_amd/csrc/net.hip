@@ -206,13 +206,6 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             return launch_bblock64(n->ops[idx - 1], op, x, y, B, queue, st);
         }
         case ROMP_OP_SEAM1X1: {
-            if (op.flags & ROMP_OPF_SEAM_TAIL) {                 // the layer's last Bottleneck: this op IS the 64 -> 256 conv, nothing follows inside the kernel
-                const float* m = resolve_in(n, op.in_buf, image);
-                const float* x = resolve_in(n, op.res_buf, image);
-                float* t = resolve_out(n, op.out_buf, center, params);
-                ROMP_REQUIRE(m && x && t, "seam1x1 (tail): bad buffers");
-                return launch_seam1x1(op, nullptr, nullptr, m, x, t, nullptr, B, st);
-            }
             ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP, "seam1x1: the op before it must be the NOP holding the first conv");
             const romp_op& a = n->ops[idx - 1];
             // ROMP_OPF_SEAM_DS: the NOP before THAT one is the downsample conv that produced the residual; the kernel runs it too
@@ -223,7 +216,7 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             float* t = resolve_out(n, a.out_buf, center, params);
             float* u = resolve_out(n, op.out_buf, center, params);
             ROMP_REQUIRE(m && x && t && u && op.in_buf == a.out_buf, "seam1x1: bad buffers");
-            return launch_seam1x1(a, &op, d, m, x, t, u, B, st);
+            return launch_seam1x1(a, op, d, m, x, t, u, B, st);
         }
         case ROMP_OP_NOP:
         case ROMP_OP_FORK:
@@ -448,8 +441,7 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
     { const int rc = conv_init(); if (rc) return rc; }
     for (int i = 1; i < n_ops; ++i)
         if (ops_host[i].kind == ROMP_OP_SEAM1X1) {
-            const bool tail = ops_host[i].flags & ROMP_OPF_SEAM_TAIL;
-            const int rc = launch_seam1x1(tail ? ops_host[i] : ops_host[i - 1], tail ? nullptr : &ops_host[i], nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            const int rc = launch_seam1x1(ops_host[i - 1], ops_host[i], nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
             if (rc) return rc;
             break;
         }
@@ -949,7 +941,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_NOP) { snprintf(out, n, "nop"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK32) { snprintf(out, n, "bblock32"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK64) { snprintf(out, n, "bblock64"); return ROMP_OK; }
-    if (op->kind == ROMP_OP_SEAM1X1) { snprintf(out, n, (op->flags & ROMP_OPF_SEAM_DS) ? "seam1x1_ds" : (op->flags & ROMP_OPF_SEAM_TAIL) ? "seam1x1_tail" : "seam1x1"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_SEAM1X1) { snprintf(out, n, (op->flags & ROMP_OPF_SEAM_DS) ? "seam1x1_ds" : "seam1x1"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }
     if (op->kind == ROMP_OP_RECORD) { snprintf(out, n, "record"); return ROMP_OK; }

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS, OPF_SEAM_TAIL, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
+from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
                   OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
 
 BN_EPS = 1e-5
@@ -305,7 +305,7 @@ def fuse_bottleneck_seams(P):
     output and x0's buffer is still intact when the seam runs (build_hrnet32_backbone frees it one conv late for this);
     env ROMP_SEAM_DS=0 keeps the downsample a launch of its own (A/B runs)."""
     import os
-    P.fused_seams = P.seam_tails = 0
+    P.fused_seams = 0
     if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_SEAMS', '1') not in ('1', 'all') or (getattr(P, 'split_k_items', 0) and os.environ.get('ROMP_FUSE_SEAMS', '1') != 'all'):
         return 0
     by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
@@ -363,22 +363,6 @@ def fuse_bottleneck_seams(P):
         P.bytes[i + 1] = 4.0 * a.H * a.W * (64 + 64 + 256 + 64)
         P.bytes[i - 1] = 0.0
         P.folded_downsamples = getattr(P, 'folded_downsamples', 0) + 1
-    # the layer's LAST Bottleneck has no next conv1 to fuse with (the transitions are 3x3): its 64 -> 256 conv + residual + ReLU runs on
-    # the same kernel in its tail form (OPF_SEAM_TAIL: GEMM 1 + epilogue only) -- the pipelined streaming loop instead of the generic
-    # 1x1 conv kernel (3.9 -> 4.8 TB/s on 1.2 GB).  env ROMP_SEAM_TAIL=0: leave it a conv (A/B runs)
-    P.seam_tails = 0
-    if os.environ.get('ROMP_SEAM_TAIL', '1') != '0':
-        for i, a in enumerate(P.ops):
-            if (a.kind == OP_CONV and a.ksize == 1 and a.stride == 1 and a.groups == 1 and a.Cin == 64 and a.Cout == 256 and a.cin_pad == 64 and
-                    a.cout_pad == 256 and a.relu and not a.relu_from and a.res_buf >= 0 and a.weight_h2 and a.scale_h2 and (a.H * a.W) % 64 == 0 and
-                    a.out_rstride == 0 and a.out_bstride == 0 and a.in_fmt == FMT_H2 and a.res_fmt == FMT_H2 and a.out_fmt == FMT_H2 and
-                    all(v % 8 == 0 for v in (a.in_cstride, a.in_coff, a.res_cstride, a.res_coff, a.out_cstride, a.out_coff))):
-                t = pack_h2_wave16(by_ptr[a.weight_h2].view(1, 4, 2, 2, 256, 8))
-                P.consts.append(t)
-                a.weight_aux = t.data_ptr()
-                a.flags |= OPF_WAVE16 | OPF_SEAM_TAIL
-                a.kind = OP_SEAM1X1
-                P.seam_tails += 1
     return P.fused_seams
 
 
@@ -500,8 +484,7 @@ def stream_races(P):
 
     def touched(i):
         op, r, w = ops[i], [], []
-        pair = op.kind in (OP_BBLOCK32, OP_BBLOCK64) or (op.kind == OP_SEAM1X1 and not (op.flags & OPF_SEAM_TAIL))
-        srcs = [op] + ([ops[i - 1]] if pair else [])             # a fused pair: the NOP before it holds the first conv
+        srcs = [op] + ([ops[i - 1]] if op.kind in (OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1) else [])    # a fused pair: the NOP before it holds the first conv
         seam_ds = op.kind == OP_SEAM1X1 and (op.flags & OPF_SEAM_DS)
         if seam_ds:                                              # the folded downsample: its input is read, its output never materialises
             r.append(ops[i - 2].in_buf)

@@ -72,9 +72,9 @@ def test_fused_block_dispatch_flag_follows_the_weight_pack():
         batch = build_romp_hrnet32(sd, 'cpu', 512, bf16x3=math)
         batch.op_array()
         fused = [i for i, o in enumerate(batch.ops) if o.kind in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1)]
-        assert len(fused) == 32 + 32 + 3 + 1                     # (+ 1: layer1's last 64 -> 256 conv on the seam kernel's tail form, round 5)
+        assert len(fused) == 32 + 32 + 3
         for i in fused:
-            for o in ((batch.ops[i],) if batch.ops[i].flags & L.OPF_SEAM_TAIL else (batch.ops[i - 1], batch.ops[i])):
+            for o in (batch.ops[i - 1], batch.ops[i]):
                 assert (o.flags & L.OPF_WAVE16) and o.weight_aux
 
 
@@ -496,17 +496,13 @@ def test_hrnet_program_fusions_are_the_documented_ones(monkeypatch):
         P.op_array()
         ks = [op.kind for op in P.ops]
         for i, k in enumerate(ks):
-            if k in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1) and not (P.ops[i].flags & L.OPF_SEAM_TAIL):
+            if k in (L.OP_BBLOCK32, L.OP_BBLOCK64, L.OP_SEAM1X1):
                 assert ks[i - 1] == L.OP_NOP, (i, P.names[i])
-            if P.ops[i].flags & L.OPF_SEAM_TAIL:                 # (round 5) the tail form: layer1's last 64 -> 256 conv, an op of its own
-                assert k == L.OP_SEAM1X1 and P.names[i].endswith('layer1.3.conv3')
             if k == L.OP_SEAM1X1 and (P.ops[i].flags & L.OPF_SEAM_DS):
                 assert ks[i - 2] == L.OP_NOP and P.names[i - 2].endswith('layer1.0.downsample') and P.ops[i - 2].out_buf == P.ops[i - 1].res_buf
                 assert P.ops[i - 2].in_buf not in (P.ops[i - 1].out_buf, P.ops[i].out_buf)      # x0 is intact while the seam reads it
         assert sum(bool(o.flags & L.OPF_SEAM_DS) for o in P.ops) == getattr(P, 'folded_downsamples', 0)
-        n_seams = sum(k == L.OP_SEAM1X1 and not (o.flags & L.OPF_SEAM_TAIL) for k, o in zip(ks, P.ops))
-        assert ks.count(L.OP_SEAM1X1) - n_seams == P.seam_tails == (1 if n_seams else 0)
-        return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), n_seams, ks.count(L.OP_FUSEUP), ks.count(L.OP_FUSESUM), ks.count(L.OP_NOP)
+        return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), ks.count(L.OP_SEAM1X1), ks.count(L.OP_FUSEUP), ks.count(L.OP_FUSESUM), ks.count(L.OP_NOP)
     for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_FUSEUP', 'ROMP_MERGE_S2', 'ROMP_SEAM_DS'):
         monkeypatch.delenv(v, raising=False)
     # round 4: 16 of the 23 fuse-layer outputs have up-terms: each runs as FUSEUP and the 18 (merged) 1x1 up-convs become NOPs
@@ -548,7 +544,7 @@ def test_committed_variant_tables_resolve(cfg):
     convs = [n for n, o in zip(P.names, P.ops) if o.kind == L.OP_CONV]
     # every conv layer has an entry; an entry beyond that must name a layer a fusion has absorbed (a NOP today: layer1.0.downsample,
     # folded into the first seam in round 5 -- its entry keeps the ROMP_SEAM_DS=0 arm of an A/B run on the same table)
-    absorbed = {n for n, o in zip(P.names, P.ops) if o.kind in (L.OP_NOP, L.OP_SEAM1X1)}      # (SEAM1X1: the tail form runs layer1.3.conv3)
+    absorbed = {n for n, o in zip(P.names, P.ops) if o.kind == L.OP_NOP}
     assert set(convs) <= set(t['layers']) and set(t['layers']) - set(convs) <= absorbed, set(convs) ^ set(t['layers'])
     variants, why = tuning.resolve_table(types.SimpleNamespace(lib=L.load(), program=P), B, t['layers'])
     assert variants is not None, why

@@ -1278,63 +1278,3 @@ def test_seam1x1_downsample(dev, B, H, monkeypatch):
     for name in ('t', 'u'):                                      # the two lowerings agree to float32 rounding (the fold adds in float32 what
         d = (outs[('1', name)] - outs[('0', name)]).abs().max().item()      # the separate launch rounds to two fp16 pieces first)
         assert d < 2e-5 * max(1.0, outs[('0', name)].abs().max().item()), (name, d)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('B,H', [(1, 16), (3, 32), (2, 128)])
-def test_seam1x1_tail(dev, B, H, monkeypatch):
-    """csrc/conv_h2x.hip, U = 0 (round 5, OPF_SEAM_TAIL): the last Bottleneck's 1x1 64 -> 256 conv + residual + ReLU, with no next
-    conv1 behind it, on the seam kernel's tail form -- against torch on the CPU and bit for bit against the conv-kernel lowering
-    (ROMP_SEAM_TAIL=0) of the same program."""
-    import ctypes as C
-    from romp_amd import lib as L
-    from romp_amd.plan import Program, Act, set_conv_math, decode_h2
-    g = torch.Generator().manual_seed(13 * B + H)
-    img = torch.randn(B, H, H, 64, generator=g)
-    dims = [(64, 256), (256, 64), (64, 256)]
-    ws = [torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5 for ci, co in dims] + [torch.randn(32, 256, 3, 3, generator=g) / 48.0]
-    sc = [torch.rand(co, generator=g) + 0.5 for _, co in dims] + [torch.rand(32, generator=g) + 0.5]
-    sh = [torch.randn(co, generator=g) * 0.2 for _, co in dims] + [torch.randn(32, generator=g) * 0.2]
-
-    def cb(t, i, res=None, pad=0):
-        y = F.conv2d(t, ws[i], None, padding=pad) * sc[i].view(1, -1, 1, 1) + sh[i].view(1, -1, 1, 1)
-        return torch.relu(y if res is None else y + res)
-    rx = cb(img.permute(0, 3, 1, 2), 0)
-    rm = cb(rx, 1)
-    rt = cb(rm, 2, res=rx)
-    outs = {}
-    for tail in ('1', '0'):
-        monkeypatch.setenv('ROMP_SEAM_TAIL', tail)
-        P = Program(dev)
-        set_conv_math(P, 'f16x2')
-        ax = P.conv('x', Act(L.BUF_IMAGE, 64, H, H, 64), [ws[0]], [sc[0]], [sh[0]], 1, 1, True)
-        am = P.conv('m', ax, [ws[1]], [sc[1]], [sh[1]], 1, 1, True)
-        at = P.conv('t', am, [ws[2]], [sc[2]], [sh[2]], 1, 1, True, res=ax)
-        av = P.conv('v', at, [ws[3]], [sc[3]], [sh[3]], 3, 1, True)         # a 3x3 reader, like transition1 (model.py:393-398)
-        ops = P.op_array()
-        kinds = [o.kind for o in P.ops]
-        assert kinds == [L.OP_CONV, L.OP_CONV, L.OP_SEAM1X1 if tail == '1' else L.OP_CONV, L.OP_CONV], kinds
-        assert P.seam_tails == int(tail) and bool(P.ops[2].flags & L.OPF_SEAM_TAIL) == (tail == '1')
-        lib = L.load()
-        h = C.c_void_p()
-        sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
-        L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
-        try:
-            xd = img.to(dev).contiguous()
-            dummy = torch.empty(16, device=dev)
-            L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
-            n = P.buf_floats[at.buf] * B
-            out = torch.empty(n, device=dev)
-            L.check(lib.romp_net_read_buffer(h, at.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
-            torch.cuda.synchronize()
-            y = decode_h2(out.cpu().reshape(B, H, H, at.C))
-            r = rt.permute(0, 2, 3, 1)
-            err = (y - r).abs().max().item() / r.abs().max().item()
-            print(f'seam1x1 tail={tail} B={B} {H}x{H}: relative err {err:.3e}')
-            assert err < 5e-5, (tail, err)
-            outs[tail] = y
-        finally:
-            lib.romp_net_destroy(h)
-    d = (outs['1'] - outs['0']).abs().max().item()
-    assert d < 2e-5 * max(1.0, outs['0'].abs().max().item()), d
-
