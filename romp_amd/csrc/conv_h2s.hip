@@ -39,17 +39,8 @@ struct SCfg {
     static constexpr int LDS_BYTES = OFF_S + 2 * SS_BYTES + 16;
     static constexpr int G = P >= 2 ? 2 : 1;                   // blocks per unit: a unit = 2G fragment reads + 3G MFMAs (accumulators alternate)
     static constexpr int PFU = 2;                              // fragment reads run PFU units ahead of their MFMAs
-    // The next stage's DMA pieces ride on the tap ends of this stage.  Rounds 3-4 spread them over ALL nine (one per tap, a second one
-    // on the first taps): the last pieces left at the very end of the stage and the stage-end drain waited their whole round trip --
-    // with one workgroup per CU (stem conv2, transition1: 48 KB stages) nothing else runs meanwhile.  Round 5: FRONT-LOADED onto the
-    // first FRONT tap ends, PPT pieces each, so that every piece has at least (9 - FRONT) / 9 of a stage to land.
-#ifndef ROMP_H2S_FRONT
-#define ROMP_H2S_FRONT 4                                       // (0: the spread schedule of rounds 3-4, for A/B builds)
-#endif
-    static constexpr int FRONT = ROMP_H2S_FRONT;
-    static constexpr int PPT = FRONT > 0 ? (NI + FRONT - 1) / FRONT : 2;
     static_assert(NS >= 1 && NS <= 4, "channel slices per workgroup");
-    static_assert(NI <= 18 && PPT <= 4, "at most two (spread) / four (front-loaded) DMA pieces per tap");
+    static_assert(NI <= 18, "at most two DMA pieces per tap");
     static_assert(4 * PLANE_U * 16 < 65536, "fragment read offsets are ds_read immediates");
 };
 
@@ -229,26 +220,17 @@ __global__ __launch_bounds__(256, 2) void conv_h2s_kernel(ConvParams p) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[j0 + g][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap][0], x[g][0], acc[j0 + g][0], 0, 0, 0);
                 const bool tap_end = u % UPT == UPT - 1;
-                int n_pieces = 0;                                  // DMA pieces riding on this tap end (compile time)
-                if (tap_end) {                                     // tap done: its registers take the next stage's weights; DMA pieces ride along
+                if (tap_end) {                                     // tap done: its registers take the next stage's weights; up to two DMA pieces ride along
                     load_w(wp, tap);
-                    if (X::FRONT > 0) {
-#pragma unroll
-                        for (int i = 0; i < X::PPT; ++i)
-                            if (tap < X::FRONT && tap * X::PPT + i < X::NI) { issue_piece(tap * X::PPT + i, nd, nbuf); ++n_pieces; }
-                    } else {
-                        if (tap < X::NI) { issue_piece(tap, nd, nbuf); ++n_pieces; }
-                        if (tap + 9 < X::NI) { issue_piece(tap + 9, nd, nbuf); ++n_pieces; }
-                    }
+                    if (tap < X::NI) issue_piece(tap, nd, nbuf);
+                    if (tap + 9 < X::NI) issue_piece(tap + 9, nd, nbuf);
                 }
                 // the order inside the unit: its look-ahead reads, its MFMAs, the memory issues of a tap end; units stay in order
                 if (u + PFU < NUNIT) __builtin_amdgcn_sched_group_barrier(0x100, 2 * G, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);
                 if (tap_end) {
-                    if (n_pieces == 4) __builtin_amdgcn_sched_group_barrier(0x010, 6, 0);
-                    else if (n_pieces == 3) __builtin_amdgcn_sched_group_barrier(0x010, 5, 0);
-                    else if (n_pieces == 2) __builtin_amdgcn_sched_group_barrier(0x010, 4, 0);
-                    else if (n_pieces == 1) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
+                    if (tap + 9 < X::NI) __builtin_amdgcn_sched_group_barrier(0x010, 4, 0);
+                    else if (tap < X::NI) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
