@@ -566,3 +566,17 @@ def test_plan_switches_stay_race_free(env, monkeypatch):
         P = build_romp_hrnet32(sd, 'cpu', 512, bf16x3='f16x2', **kw)
         P.op_array()
         assert stream_races(P) == []
+
+
+def test_counted_waits_are_covered_by_the_compiled_kernels():
+    """Round 5: the seam kernel ends a tile on `s_waitcnt vmcnt(52)` / `vmcnt(20)` instead of a full drain -- right only while the
+    COMPILED tile loop issues at least that many vector-memory instructions after the next tile's DMA (a wave's memory operations
+    retire in issue order).  hipcc may merge or split loads and stores: scripts/check_counted_waits.py compiles csrc/conv_h2x.hip to
+    assembly and counts (the fused-block kernels' vmcnt(6) / vmcnt(3) take a minute each to compile: `python
+    scripts/check_counted_waits.py h2c h2c32`, run by hand when conv_h2c.h changes)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'check_counted_waits.py'), 'h2x'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(' ok') == 2 and 'NOT COVERED' not in r.stdout, r.stdout
+
