@@ -4,7 +4,9 @@
 # branch streams ON and the timeline of the concurrent job.
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$REPO"; mkdir -p gpurun_out; export PYTHONUNBUFFERED=1
-timeout 120 scripts/micro/_bin/wino_step_bench > gpurun_out/r05_wino_step_bench.txt 2>&1; echo "== wino_step_bench exit $?"; cat gpurun_out/r05_wino_step_bench.txt
+if [ -x scripts/micro/_bin/wino_step_bench ]; then       # (first session of the round; the binary is built by hand from scripts/micro/wino_step_bench.hip)
+  timeout 120 scripts/micro/_bin/wino_step_bench > gpurun_out/r05_wino_step_bench.txt 2>&1; echo "== wino_step_bench exit $?"; cat gpurun_out/r05_wino_step_bench.txt
+fi
 timeout 900 python bench.py > gpurun_out/r05_bench.log 2>&1; echo "== bench: exit $?"
 grep '^{' gpurun_out/r05_bench.log | tail -1 > gpurun_out/r05_bench.json
 python - <<'PY'
@@ -28,3 +30,6 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_tl -
 echo "== batch trace exit $? :: $(grep -o '"value": [0-9.]*' $REPO/gpurun_out/r05_trace_run.log | head -1)"
 f=$(find /tmp/rp_tl -name "*kernel_trace.csv" | head -1)
 python $REPO/scripts/timeline.py "$f" 4 | tee $REPO/gpurun_out/r05_timeline_b32.txt | head -12
+# the last forward kernel by kernel, and the engine clock / socket power the job sustains (second session)
+python $REPO/scripts/timeline.py "$f" 4 $REPO/gpurun_out/r05_timeline_kernels.txt > /dev/null
+cd $REPO && bash scripts/gpu_clocks.sh
