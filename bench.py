@@ -447,6 +447,8 @@ def bev_parity_report(model, images, sd, thresh, pick=(0, 7, 19, 31)):
     from oracle import romp_oracle as O, bev_oracle as BO
     torch.set_num_threads(usable_cores())
     pick = [p for p in pick if p < images.shape[0]]
+    if 'coordmap_3d' not in sd:                                  # the oracle's constant buffer (bev/model.py:9-17); the product's synthetic
+        sd = dict(sd, coordmap_3d=BO.coordmap_3d())              # state_dict has the learnable tensors only
     c3d, cam3d = model.model.localization(images)
     out = model.model(images)
     torch.cuda.synchronize()
