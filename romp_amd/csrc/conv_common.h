@@ -47,7 +47,9 @@ struct ConvParams {
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
                               // 512 (h2r / h2s, correct outputs) the LDS-transposed epilogue instead of the direct one,
                               // 16 skip a stage barrier (f32 kernel), 32 return at once (launch cost), 64 / 128 (bxd) skip
-                              // only the pixel loads / only the weight DMA.  scripts/conv_ablate.py and DESIGN.md §4 use them.
+                              // only the pixel loads / only the weight DMA; 64 (h2r): every weight fragment load re-reads the first
+                              // tap's 2 KB (same instructions, no weight stream from L2).  scripts/conv_ablate.py, conv_sweep.py and
+                              // DESIGN.md §4 use them.
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -108,11 +108,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
         d_rc[k] = row | (col << 8) | ((row < C::HR && col < C::HC) ? 1 << 16 : 0) | (w << 17);
     }
     const int cold = (p.dbg & 1) ? 0 : 1;                      // ablation bit 1: every DMA piece reads the zero page (no HBM traffic)
+    const int wcold = (p.dbg & 64) ? 0 : 1;                    // ablation bit 64: every weight fragment load re-reads the FIRST tap's 2 KB of the
+                                                               // wave's slice (same instruction stream, L1 hits: no weight traffic from L2)
 
     auto make_desc = [&](const Item& it, int c0) {
         RStage d;
         d.in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs + c0;
-        d.wg = p.wh + (size_t)it.g * (9 * cin16 * 4 * p.cout_pad) + (c0 >> 4) * 4 * p.cout_pad + it.n0 + sl * 32;
+        d.wg = p.wh + (size_t)it.g * (9 * cin16 * 4 * p.cout_pad) + wcold * (c0 >> 4) * 4 * p.cout_pad + it.n0 + sl * 32;
         d.iy0 = it.ty * C::TH - p.pad_h;
         d.ix0 = it.tx * TW - p.pad_w;
         d.c0 = c0;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
     // weight fragments of one tap: lane (li, lh) holds channel li of the slice, k-half lh
     frag wreg[9][2];
     const unsigned w_lane = (unsigned)(lh * p.cout_pad + li);
-    const unsigned w_tap = (unsigned)(cin16 * 4 * p.cout_pad), w_pc = (unsigned)(2 * p.cout_pad);   // unit strides of a tap / a piece
+    const unsigned w_tap = (unsigned)(wcold * cin16 * 4 * p.cout_pad), w_pc = (unsigned)(2 * p.cout_pad);   // unit strides of a tap / a piece
     // `wp` walks the taps in order (a running per-lane pointer: two strides in SGPRs instead of eighteen hoisted offsets)
     auto load_w = [&](const uint4*& wp, int tap) {
         wreg[tap][0] = __builtin_bit_cast(frag, wp[0]);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
             };
             // a tap's registers are re-loaded right after its last MFMA of a sub-stage: with the weights of the NEXT sub-stage (the
             // same stage's second 16 channels: one chunk = 4 * cout_pad units further on), or of the next stage's first
-            const uint4* wp = (KSUB == 2 ? cwg + 4 * p.cout_pad : nd.wg) + w_lane;
+            const uint4* wp = (KSUB == 2 ? cwg + wcold * 4 * p.cout_pad : nd.wg) + w_lane;
             const uint4* wp2 = nd.wg + w_lane;
 #pragma unroll
             for (int u = 0; u < PFU; ++u) read_x(u);
