@@ -1,5 +1,5 @@
 // conv_h2x.hip -- the seam between two Bottlenecks of HRNet's layer1 (simple_romp/romp/model.py:103-123) as ONE kernel
-// (plan.fuse_bottleneck_seams, ROMP_OP_SEAM1X1; written at the end of round 3: first version, not tuned).
+// (plan.fuse_bottleneck_seams, ROMP_OP_SEAM1X1; round 3, the tile loop re-done in round 5).
 //     t = relu(bn3(conv1x1_{64->256}(m)) + x)        the last conv of Bottleneck i (residual x, 256 channels)
 //     u = relu(bn1'(conv1x1_{256->64}(t)))           the first conv of Bottleneck i + 1
 // Both are 1x1 convs on 256-channel 128^2 tensors and HBM-bound (4.3-4.5 TB/s as separate launches, 1.7 ms of an 11.8 ms forward
@@ -17,6 +17,7 @@
 // in LDS), and the tile ends on a COUNTED wait, vmcnt(52): a wave's memory operations retire in issue order and 16 t stores + 32
 // residual loads + 4 u stores were issued after the DMA, so "at most 52 outstanding" means the next m has landed while the stores
 // and the next residual (used after the next GEMM 1; hipcc counts that wait itself) stay in flight across the barrier.
+// (scripts/check_counted_waits.py -- a CPU test runs it -- counts the vector-memory instructions of the COMPILED loop against that 52.)
 //
 // DS = 1 (round 5, ROMP_OPF_SEAM_DS): the seam behind Bottleneck 0, whose residual is not a tensor but a conv of its own -- the
 // `downsample` branch, bn_d(conv1x1_{64->256}(x0)) on the block input x0 (model.py:289-301) -- folded in:
