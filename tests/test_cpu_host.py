@@ -580,3 +580,45 @@ def test_counted_waits_are_covered_by_the_compiled_kernels():
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(' ok') == 2 and 'NOT COVERED' not in r.stdout, r.stdout
 
+
+def test_downsample_fold_needs_an_intact_block_input(monkeypatch):
+    """plan.fuse_bottleneck_seams (round 5, OPF_SEAM_DS) lets the seam kernel compute Bottleneck 0's downsample conv from the block
+    input x0 -- legal only while x0's arena buffer is still intact when the seam runs and nobody else reads the downsample's output.
+    Same five convs, three lowerings: x0 kept (fold), x0 freed right after the downsample so that a later tensor re-uses its buffer
+    (no fold: plain seam), a second reader of the downsample output (no fold)."""
+    import torch
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math
+    for v in ('ROMP_FUSE_SEAMS', 'ROMP_SEAM_DS'):
+        monkeypatch.delenv(v, raising=False)
+    g = torch.Generator().manual_seed(3)
+    H = 16
+    dims = [(64, 64), (64, 64), (64, 256), (64, 256), (256, 64), (256, 64)]
+    ws = [torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5 for ci, co in dims]
+    sc = [torch.ones(co) for _, co in dims]
+    sh = [torch.zeros(co) for _, co in dims]
+
+    def lower(free_x0_early, second_reader):
+        P = Program('cpu')
+        set_conv_math(P, 'f16x2')
+        a0 = P.conv('x0', Act(L.BUF_IMAGE, 64, H, H, 64), [ws[0]], [sc[0]], [sh[0]], 1, 1, True)
+        am = P.conv('m', a0, [ws[1]], [sc[1]], [sh[1]], 1, 1, True)
+        ad = P.conv('d', a0, [ws[2]], [sc[2]], [sh[2]], 1, 1, False)
+        if free_x0_early:
+            P.free(a0)
+        at = P.conv('t', am, [ws[3]], [sc[3]], [sh[3]], 1, 1, True, res=ad)
+        au = P.conv('u', at, [ws[4]], [sc[4]], [sh[4]], 1, 1, True)
+        if second_reader:
+            P.conv('u2', ad, [ws[5]], [sc[5]], [sh[5]], 1, 1, True)
+        P.op_array()
+        return P, a0, at, au
+    P, a0, at, au = lower(False, False)
+    assert P.fused_seams == 1 and getattr(P, 'folded_downsamples', 0) == 1
+    assert [o.kind for o in P.ops[:5]] == [L.OP_CONV, L.OP_CONV, L.OP_NOP, L.OP_NOP, L.OP_SEAM1X1] and P.ops[4].flags & L.OPF_SEAM_DS
+    P, a0, at, au = lower(True, False)
+    assert a0.buf in (at.buf, au.buf), 'the early free was meant to make a later tensor re-use the buffer of x0'
+    assert P.fused_seams == 1 and getattr(P, 'folded_downsamples', 0) == 0 and P.ops[2].kind == L.OP_CONV
+    assert not (P.ops[4].flags & L.OPF_SEAM_DS)
+    P, a0, at, au = lower(False, True)
+    assert P.fused_seams == 1 and getattr(P, 'folded_downsamples', 0) == 0 and P.ops[2].kind == L.OP_CONV
+
