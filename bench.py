@@ -75,6 +75,9 @@ def parse_args():
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the extra conv_math=f32 timing of the same workload')
     ap.add_argument('--no-latency', action='store_true', help='skip the single-image ROMP(settings)(frame) latency leg')
     ap.add_argument('--with-verts', type=int, default=0, help='N>1: also all-gather the 6890x3 vertices')
+    ap.add_argument('--preheat-cap', type=float, default=10.0,
+                    help='seconds: UNcounted pre-heat steps in front of --warmup until two consecutive steps agree within 1 %% '
+                         '(a fresh box runs its first steps slowly); 0: none.  The timed region stays exactly --steps steps')
     return ap.parse_args()
 
 
@@ -563,6 +566,97 @@ def bench_bev(args, dev):
     print(json.dumps(res), flush=True)
 
 
+
+# ------------------------------------------------------------------------------------------------ clocks / power / per-step times
+class GpuSensors:
+    """Engine clock (MHz) and socket power (W) of one device, sampled by a background thread while the timed region runs -- the line
+    then says at what clock the number was taken (this job is power-limited: 2.2 GHz of the nominal 2.4 at 1.3 kW of the 1.4-kW cap,
+    profiles/r05_clocks_power.txt).  Sources, first that answers: the amdgpu hwmon files of the device's PCI function
+    (freq1_input = current sclk in Hz, power1_average / power1_input in microwatts: two file reads per sample, no subprocess),
+    else `rocm-smi --showclocks --showpower` (the sampler of scripts/gpu_clocks.sh).  No source -> empty summaries, never an error."""
+
+    def __init__(self, device_index, period=0.1):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
+        self.index, self.source, self._files = device_index, None, None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hw = sorted(glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*' % bdf))
+            if hw:
+                fr = os.path.join(hw[0], 'freq1_input')
+                pw = [f for f in (os.path.join(hw[0], 'power1_average'), os.path.join(hw[0], 'power1_input')) if os.path.exists(f)]
+                if os.path.exists(fr) and self._read(fr) is not None:
+                    self._files = (fr, pw[0] if pw and self._read(pw[0]) is not None else None)
+                    self.source = 'sysfs hwmon (%s)' % bdf
+        except Exception:                              # noqa: BLE001 -- a sensor is optional
+            self._files = None
+        if self._files is None:
+            import shutil
+            if shutil.which('rocm-smi'):
+                self.source, self.period = 'rocm-smi --showclocks --showpower', max(period, 0.25)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:                              # noqa: BLE001
+            return None
+
+    def _sample(self):
+        if self._files is not None:
+            fr, pw = self._files
+            hz = self._read(fr)
+            uw = self._read(pw) if pw else None
+            return (None if hz is None else hz / 1e6, None if uw is None else uw / 1e6)
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(['rocm-smi', '-d', str(self.index), '--showclocks', '--showpower'], capture_output=True, text=True, timeout=5).stdout
+        except Exception:                              # noqa: BLE001
+            return (None, None)
+        sc = re.search(r'sclk clock level: \S+ \((\d+)Mhz\)', out)
+        pw = re.search(r'Power \(W\): ([0-9.]+)', out)
+        return (float(sc.group(1)) if sc else None, float(pw.group(1)) if pw else None)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append(self._sample())
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if self.source is None:
+            return self
+        self.samples, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=6)
+            self._thread = None
+        return self.summary()
+
+    def summary(self):
+        out = {'clock_mhz': None, 'power_w': None, 'sensor_source': self.source, 'sensor_samples': len(self.samples)}
+        for key, col in (('clock_mhz', 0), ('power_w', 1)):
+            v = sorted(s[col] for s in self.samples if s[col] is not None)
+            if v:
+                out[key] = {'median': round(v[len(v) // 2], 1), 'min': round(v[0], 1), 'max': round(v[-1], 1)}
+        return out
+
+
+def step_stats(ms):
+    v = sorted(ms)
+    return {'min': round(v[0], 3), 'median': round(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3),
+            'max': round(v[-1], 3), 'all': [round(x, 3) for x in ms]}
+
+
 # ------------------------------------------------------------------------------------------------ headline
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks of this same command under
@@ -579,29 +673,74 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
-def timed_steps(step, warmup, steps, dev, world):
-    """The contract's timing discipline: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier and a device
-    synchronisation on both sides; the MAX over ranks is the job's time."""
+def preheat(step, dev, world, cap_s=10.0, tol=0.01, max_steps=40):
+    """UNcounted steps in front of the warm-up until two consecutive ones agree within `tol` (cap `cap_s` seconds): a fresh lease
+    runs its first steps slowly (clock ramp, first-touch page tables, code-object loads -- profiles/r05_notes.md section 8 saw 15-20 %
+    on every kernel of the sweep that ran first), and the driver's bench IS the first thing a fresh box runs.  Every rank takes the
+    same decision (the step times are MAX-reduced first).  -> (seconds spent, [ms of every pre-heat step])."""
     sync = (lambda: torch.cuda.synchronize(dev)) if dev.type == 'cuda' else (lambda: None)
+    ms, t_start = [], time.perf_counter()
+    spent = 0.0
+    while len(ms) < max_steps:
+        sync()
+        t0 = time.perf_counter()
+        step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ms.append(dt * 1e3)
+        spent += dt
+        if (len(ms) >= 2 and abs(ms[-1] - ms[-2]) <= tol * ms[-1]) or spent >= cap_s:
+            break
+    return time.perf_counter() - t_start, ms
+
+
+def timed_steps(step, warmup, steps, dev, world, sensors=None):
+    """The contract's timing discipline: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier and a device
+    synchronisation on both sides; the MAX over ranks is the job's time.  Inside the bracket nothing is added but one event record
+    per step on the launch stream (and a host clock read): -> (seconds, {'host': [...], 'gpu': [...]} per-step milliseconds of this
+    rank -- host = between the returns of consecutive step() calls, gpu = between the events; a step's last SMPL launch may still
+    be running when step() returns, so single entries can trade a fraction of a millisecond with their neighbour; the sums are the
+    bracket's time).  `sensors` (GpuSensors) sample clock / power during exactly the bracket."""
+    cuda = dev.type == 'cuda'
+    sync = (lambda: torch.cuda.synchronize(dev)) if cuda else (lambda: None)
     for _ in range(warmup):
         step()
     sync()
     if world > 1:
         dist.barrier()
     sync()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if cuda else None
+    host = [0.0] * (steps + 1)
+    if sensors is not None:
+        sensors.start()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    host[0] = t0
+    if cuda:
+        ev[0].record()
+    for i in range(steps):
         step()
+        if cuda:
+            ev[i + 1].record()
+        host[i + 1] = time.perf_counter()
     sync()
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    if sensors is not None:
+        sensors.stop()
+    per = {'host': [(host[i + 1] - host[i]) * 1e3 for i in range(steps)]}
+    if cuda:
+        per['gpu'] = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt
+    return dt, per
 
 
 def collective_info(world, dev):
@@ -618,9 +757,10 @@ def collective_info(world, dev):
     return info
 
 
-def run_job(args, model, images, lo, rank, world, dev, D):
+def run_job(args, model, images, lo, rank, world, dev, D, sensors=None):
     """The timed job of the headline line: every rank walks its resident shard in calls of --batch images (net + parse + SMPL);
-    N > 1: one all-gather of the per-person records per step.  -> (seconds for args.steps steps (max over ranks), persons)."""
+    N > 1: one all-gather of the per-person records per step.  -> (seconds for args.steps steps (max over ranks), persons,
+    timing record: per-step times, the pre-heat's steps)."""
     B = args.batch
     persons = [0]
 
@@ -631,11 +771,15 @@ def run_job(args, model, images, lo, rank, world, dev, D):
         else:
             rec = D.local_records(model, images, lo, chunk=B, with_joints=True, with_verts=bool(args.with_verts))
             persons[0] = 0 if rec is None else rec.shape[0]
-    dt = timed_steps(step, args.warmup, args.steps, dev, world)
-    return dt, persons[0]
+    pre_s, pre_ms = preheat(step, dev, world, cap_s=getattr(args, 'preheat_cap', 10.0)) if getattr(args, 'preheat_cap', 10.0) > 0 else (0.0, [])
+    dt, per = timed_steps(step, args.warmup, args.steps, dev, world, sensors)
+    timing = {'preheat_s': round(pre_s, 3), 'preheat_step_ms': [round(x, 3) for x in pre_ms],
+              'step_ms': step_stats(per.get('gpu', per['host'])), 'step_ms_clock': 'HIP events on the launch stream' if 'gpu' in per else 'host',
+              'step_ms_host': step_stats(per['host'])}
+    return dt, persons[0], timing
 
 
-def headline_result(args, dt, persons, G, n_local, world, dev, variant_table):
+def headline_result(args, dt, persons, G, n_local, world, dev, variant_table, timing=None, sensors=None):
     B = args.batch
     strong = args.global_batch > 0
     bb = 'HRNet-32' if args.backbone == 'hrnet32' else 'ResNet-50'
@@ -652,13 +796,22 @@ def headline_result(args, dt, persons, G, n_local, world, dev, variant_table):
            'autotune': bool(args.autotune), 'variant_table': variant_table, 'branch_streams': bool(args.streams),
            'conv_math': args.conv_math, 'parallelism': 'dp%d' % world}
     cfg.update(collective_info(world, dev))
-    return {
+    res = {
         'metric': 'images/sec (512x512, %s)' % bb, 'value': round(G * args.steps / dt, 2), 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.conv_math == 'f32' else 'f32 (convs as %s-split products, f32 accumulate; same 1e-4 parity gate as f32 MFMA)' % args.conv_math,
         'data': 'synthetic', 'config': cfg,
     }
+    # what the number was taken under (rank 0's view): every timed step's duration, the un-counted pre-heat in front of the warm-up
+    # (its step times show a cold box warming up), engine clock / socket power sampled during exactly the timed steps
+    if timing is not None:
+        res.update(step_ms=timing['step_ms'], preheat_s=timing['preheat_s'], preheat_step_ms=timing['preheat_step_ms'])
+        res['step_ms']['clock'] = timing['step_ms_clock']
+        res['step_ms_host'] = timing['step_ms_host']
+    if sensors is not None:
+        res.update(sensors.summary())
+    return res
 
 
 def install_variants(args, net, B, rank, backbone, log):
@@ -747,9 +900,10 @@ def main():
                 t_lo, t_hi = (mid, t_hi) if kept > 14.0 else (t_lo, mid)
         args.center_thresh = round(mid, 4)
 
+    sensors = GpuSensors(local_rank) if rank == 0 else None
     with torch.cuda.stream(stream):
-        dt, persons = run_job(args, model, images, lo, rank, world, dev, D)
-    result = headline_result(args, dt, persons, G, n_local, world, dev, variant_table)
+        dt, persons, timing = run_job(args, model, images, lo, rank, world, dev, D, sensors)
+    result = headline_result(args, dt, persons, G, n_local, world, dev, variant_table, timing, sensors)
     if rank == 0:
         first = images[:B]
         if args.dump_op_kernels:

@@ -37,7 +37,7 @@ extern "C" {
 #define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
 #define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
 
-#define ROMP_ABI_VERSION 5
+#define ROMP_ABI_VERSION 6   /* 6: ROMP_OPF_SEAM_DS / unknown flag bits rejected, romp_net_plan_kind, romp_parse_watch, romp_net_sat_counter */
 
 int         romp_abi_version(void);
 const char* romp_last_error(void);
@@ -112,6 +112,8 @@ const char* romp_last_error(void);
                                    its 256-channel output tensor is never written                                        */
 #define ROMP_OPF_STEM_VALU  2   /* STEM: take the float32 VALU kernel even for an H2 output (A/B runs, tests; also chosen
                                    when 256 * |w| does not fit the fp16 pieces of the MFMA form)                      */
+
+#define ROMP_OPF_ALL        7   /* every bit defined above: romp_net_create refuses a program with any other bit set */
 
 typedef struct romp_op {
     int32_t kind;
@@ -223,6 +225,9 @@ int  romp_net_range_scan(romp_net* net, const float* image_nhwc, int B, float* c
  * and every romp_net_range_scan.  romp_net_saturated synchronises `stream`. */
 int  romp_net_saturated(romp_net* net, int64_t* count_host, int reset, void* stream);
 int  romp_net_set_sat_check(romp_net* net, int enable);
+/* Device address of that counter (an int32, cumulative like romp_net_saturated without reset): what romp_parse_watch's `watch`
+ * argument is for -- the default-on range guard of the Python API reads it with the detection count, for free (main.py). */
+const int32_t* romp_net_sat_counter(romp_net* net);
 void romp_net_destroy(romp_net* net);
 
 /* Stand-alone conv launcher (tests / microbenchmarks of one layer).  variant < 0: heuristic. */
@@ -255,6 +260,19 @@ int  romp_parse(const float* center_maps, const float* params_maps_nhwc, int B,
                 int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
                 float* cam, float* thetas, float* betas, int32_t* center_preds,
                 int32_t* workspace /* B*(2*max_person+2) int32 */, void* stream);
+/* romp_parse with a WATCHED device word riding on the count read-back: the packing kernel copies *watch (an int32 on the device;
+ * the API passes romp_net_sat_counter(net)) into workspace[B*(2*max_person+2)], and with count_host != NULL it comes back in
+ * *watch_host inside the SAME device-to-host copy and synchronisation as the counts (count_host == NULL: it stays in the
+ * workspace for the caller's own download).  The reference's network is float32 and has no range to leave
+ * (simple_romp/romp/main.py:106-115); the f16x2 kernels clamp beyond 65504 / 2^act_shift, and this is how every forward of the API
+ * learns -- without a second round trip -- whether one did, so that it can re-run the call on the exact-f32 program.
+ * workspace: B*(2*max_person+2) + 2 int32.  watch == NULL: exactly romp_parse. */
+int  romp_parse_watch(const float* center_maps, const float* params_maps_nhwc, int B,
+                      float conf_thresh, int max_person, int32_t* count_host,
+                      int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+                      float* cam, float* thetas, float* betas, int32_t* center_preds,
+                      int32_t* workspace /* B*(2*max_person+2) + 2 int32 */, void* stream,
+                      const int32_t* watch, int32_t* watch_host);
 /* rot6D_to_angular (utils.py:471-475): x6 (n,6) -> aa (n,3) */
 int  romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream);
 

@@ -22,7 +22,7 @@ from torch import nn
 
 from . import lib as L
 from .bev_plan import DEPTH, MAP, build_bev_hrnet32, cam3dmap_anchor
-from .net import RompNet
+from .net import RangeGuard, RompNet
 from .smpl import SMPL
 from .utils import convert_tensor2numpy, determine_device, img_preprocess_device
 
@@ -107,6 +107,7 @@ class BEVv1(object):
         self.net = RompNet(state_dict, self.device, max_batch=max_batch, builder=build_bev_hrnet32,
                            out_shapes=((DEPTH, MAP, MAP), (3, DEPTH, MAP, MAP)), bf16x3=bf16x3)
         self.centermap_parser = CenterMap3D(center_thresh)
+        self.range_guard = RangeGuard(self.net)                # default-on, as in ROMP (net.RangeGuard)
         f = lambda k: state_dict[k].detach().float()
         dv = lambda t: t.contiguous().to(self.device)
         self.emb = dv(f('position_embeddings.weight'))
@@ -123,8 +124,16 @@ class BEVv1(object):
     def __call__(self, images):
         """images (B,512,512,3) float on device -> dict like BEVv1.forward (:247-249) or None."""
         lib = L.load()
+        net = self.net
         c3d, cam3d = self.localization(images)
         bids, czyx, confs = self.centermap_parser.parse_3dcentermap(c3d)
+        # range guard: the parse has just synchronised on the count, so the network is done -- one 4-byte read of its saturation
+        # counter; if it moved, the whole call again on the exact-f32 program (whose front-view features the regression then reads)
+        if self.range_guard.enabled and self.range_guard.check(net.saturated):
+            net = self.net.f32_twin()
+            c3d, cam3d = net.forward_nhwc(images)
+            self.range_guard.warn(images)
+            bids, czyx, confs = self.centermap_parser.parse_3dcentermap(c3d)
         N = bids.shape[0]
         if N == 0:
             print('No person detected!')
@@ -136,8 +145,8 @@ class BEVv1(object):
                'cam_trans': torch.empty(N, 3, **f32)}
         cam_czyx = torch.empty(N, 3, device=dev, dtype=torch.int32)
         b32, z32 = bids.int().contiguous(), czyx.int().contiguous()
-        P = self.net.program
-        feat_ptr = self.net.buffer_ptr(P.fv_buf) + 4 * P.fv_coff
+        P = net.program
+        feat_ptr = net.buffer_ptr(P.fv_buf) + 4 * P.fv_coff
         with torch.cuda.device(dev):
             L.check(lib.romp_bev_regress(L.ptr(cam3d), C.c_void_p(feat_ptr), P.fv_cstride, N, L.ptr(b32), L.ptr(z32),
                                          self.anchors, L.ptr(self.emb), L.ptr(self.w1t), L.ptr(self.b1), L.ptr(self.w2t),

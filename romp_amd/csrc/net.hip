@@ -209,8 +209,9 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP, "seam1x1: the op before it must be the NOP holding the first conv");
             const romp_op& a = n->ops[idx - 1];
             // ROMP_OPF_SEAM_DS: the NOP before THAT one is the downsample conv that produced the residual; the kernel runs it too
+            ROMP_REQUIRE(!(op.flags & ROMP_OPF_SEAM_DS) || idx >= 2, "seam1x1: ROMP_OPF_SEAM_DS needs two ops in front of it");
             const romp_op* d = (op.flags & ROMP_OPF_SEAM_DS) ? &n->ops[idx - 2] : nullptr;
-            ROMP_REQUIRE(!d || (idx > 1 && d->kind == ROMP_OP_NOP), "seam1x1: the op two before it must be the NOP holding the downsample conv");
+            ROMP_REQUIRE(!d || d->kind == ROMP_OP_NOP, "seam1x1: the op two before it must be the NOP holding the downsample conv");
             const float* m = resolve_in(n, a.in_buf, image);
             const float* x = resolve_in(n, d ? d->in_buf : a.res_buf, image);
             float* t = resolve_out(n, a.out_buf, center, params);
@@ -475,6 +476,14 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
         for (int k = 0; k < 4; ++k) reads |= ((o.kind == ROMP_OP_FUSESUM || o.kind == ROMP_OP_FUSEUP) && k < o.n_terms && o.term_buf[k] == ROMP_BUF_IMAGE);
         if (reads) n->image_only_in_op0 = false;
     }
+    // a flag bit this build does not know changes what an op MEANS (ROMP_OPF_SEAM_DS: the residual tensor is never written): a
+    // program lowered for a newer ABI must fail here, not run as something else
+    for (int i = 0; i < n_ops; ++i)
+        if (n->ops[i].flags & ~ROMP_OPF_ALL) {
+            set_error("op %d: unknown flag bits 0x%x (library ABI %d)", i, n->ops[i].flags & ~ROMP_OPF_ALL, ROMP_ABI_VERSION);
+            romp_net_destroy(n);
+            return ROMP_EINVAL;
+        }
     n->bufs.resize(n_bufs, nullptr);
     for (int i = 0; i < n_bufs; ++i) {
         const size_t bytes = (size_t)buf_floats[i] * max_batch * sizeof(float);
@@ -866,7 +875,10 @@ int romp_net_saturated(romp_net* n, int64_t* count_host, int reset, void* stream
     return ROMP_OK;
 }
 
-// 1: the fused BasicBlock kernels run their counting builds too (a few percent slower; default: env ROMP_CHECK_FINITE=1).
+// Device address of the counter: romp_parse_watch reads it back with the detection counts (the API's default-on range guard).
+const int32_t* romp_net_sat_counter(romp_net* n) { return n ? (const int32_t*)n->sat : nullptr; }
+
+// 1: the fused BasicBlock kernels run their counting builds too (default: env ROMP_CHECK_FINITE=1; the API's range guard turns it on).
 int romp_net_set_sat_check(romp_net* n, int enable) {
     ROMP_REQUIRE(n, "romp_net_set_sat_check: null net");
     n->sat_checked = enable != 0;

@@ -80,10 +80,14 @@ __global__ __launch_bounds__(PARSE_THREADS) void parse_nms_topk_kernel(const flo
 
 __global__ __launch_bounds__(64) void parse_pack_kernel(
     const float* __restrict__ center, const float* __restrict__ params, int B, int max_person,
-    const int32_t* __restrict__ ws, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
-    float* cam, float* thetas, float* betas, int32_t* center_preds) {
+    int32_t* __restrict__ ws, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+    float* cam, float* thetas, float* betas, int32_t* center_preds, const int32_t* watch) {
     const int r = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int stride = 2 * max_person + 2;
+    // romp_parse_watch: the watched word (the net's saturation counter, bumped by agent-scope atomics of kernels that may still be
+    // running on another stream) rides behind the counts; nobody else touches that workspace slot
+    if (watch && r == 0 && b == 0 && lane == 0)
+        ws[(size_t)B * stride] = __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int cnt = ws[(size_t)b * stride + 2 * max_person];
     if (r >= cnt) return;
     int off = 0;
@@ -258,9 +262,10 @@ int romp_project_verts(const float* verts, int N, int V, const float* cam, const
     return ROMP_OK;
 }
 
-int romp_parse(const float* center_maps, const float* params_maps, int B, float conf_thresh, int max_person,
-               int32_t* count_host, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
-               float* cam, float* thetas, float* betas, int32_t* center_preds, int32_t* workspace, void* stream) {
+int romp_parse_watch(const float* center_maps, const float* params_maps, int B, float conf_thresh, int max_person,
+                     int32_t* count_host, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+                     float* cam, float* thetas, float* betas, int32_t* center_preds, int32_t* workspace, void* stream,
+                     const int32_t* watch, int32_t* watch_host) {
     ROMP_REQUIRE(center_maps && params_maps && workspace && B > 0, "romp_parse: bad arguments");
     ROMP_REQUIRE(max_person >= 1 && max_person <= 1024, "romp_parse: max_person %d out of range", max_person);
     ROMP_REQUIRE(batch_ids && flat_inds && scores && params_pred && cam && thetas && betas && center_preds,
@@ -269,16 +274,25 @@ int romp_parse(const float* center_maps, const float* params_maps, int B, float 
     hipLaunchKernelGGL(parse_nms_topk_kernel, dim3(B), dim3(PARSE_THREADS), 0, st, center_maps, conf_thresh, max_person, workspace);
     ROMP_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(parse_pack_kernel, dim3(max_person, B), dim3(64), 0, st, center_maps, params_maps, B, max_person,
-                       workspace, batch_ids, flat_inds, scores, params_pred, cam, thetas, betas, center_preds);
+                       workspace, batch_ids, flat_inds, scores, params_pred, cam, thetas, betas, center_preds, watch);
     ROMP_HIP_CHECK(hipGetLastError());
     if (!count_host) return ROMP_OK;     // asynchronous form: image b's count stays in workspace[b * (2 * max_person + 2) + 2 * max_person]
-    std::vector<int32_t> cnt((size_t)B * (2 * max_person + 2));
-    ROMP_HIP_CHECK(hipMemcpyAsync(cnt.data(), workspace, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    const size_t n_cnt = (size_t)B * (2 * max_person + 2);
+    std::vector<int32_t> cnt(n_cnt + 1);                                     // (+ the watched word, when there is one: the same copy)
+    ROMP_HIP_CHECK(hipMemcpyAsync(cnt.data(), workspace, (n_cnt + (watch ? 1 : 0)) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     ROMP_HIP_CHECK(hipStreamSynchronize(st));
     int total = 0;
     for (int b = 0; b < B; ++b) total += cnt[(size_t)b * (2 * max_person + 2) + 2 * max_person];
     *count_host = total;
+    if (watch && watch_host) *watch_host = cnt[n_cnt];
     return ROMP_OK;
+}
+
+int romp_parse(const float* center_maps, const float* params_maps, int B, float conf_thresh, int max_person,
+               int32_t* count_host, int32_t* batch_ids, int32_t* flat_inds, float* scores, float* params_pred,
+               float* cam, float* thetas, float* betas, int32_t* center_preds, int32_t* workspace, void* stream) {
+    return romp_parse_watch(center_maps, params_maps, B, conf_thresh, max_person, count_host, batch_ids, flat_inds, scores, params_pred,
+                            cam, thetas, betas, center_preds, workspace, stream, nullptr, nullptr);
 }
 
 int romp_rot6d_to_aa(const float* x6, int n, float* aa, void* stream) {

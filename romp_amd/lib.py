@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ROMP_HIP_LIB') or os.path.join(_HERE, 'libromp_hip.so')     # (ROMP_HIP_LIB: a debug build of the same ABI)
 
-ABI_VERSION = 5          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
+ABI_VERSION = 6          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
 FMT_F32, FMT_H2 = 0, 1
 OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN, OP_BEV_PACK, OP_BEV_MAPS, OP_CONV3D = 1, 2, 3, 4, 5, 6, 7, 8
@@ -102,6 +102,8 @@ def load():
         'romp_bev_regress': (C.c_int, [vp, vp, i32, i32, vp, vp, C.POINTER(C.c_float)] + [vp] * 7 + [vp] * 6 + [vp]),
         'romp_net_buffer_ptr': (C.c_void_p, [vp, i32]),
         'romp_parse': (C.c_int, [vp, vp, i32, f, i32, C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'romp_parse_watch': (C.c_int, [vp, vp, i32, f, i32, C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]),
+        'romp_net_sat_counter': (C.c_void_p, [vp]),
         'romp_rot6d_to_aa': (C.c_int, [vp, i32, vp, vp]),
         'smpl_ctx_create': (C.c_int, [C.POINTER(vp), vp, vp, i32, vp, vp, vp, i64p, vp, vp, i64p, i32, vp]),
         'smpl_forward': (C.c_int, [vp, vp, i32, vp, i32, i32, vp, vp, vp]),
@@ -111,12 +113,16 @@ def load():
         'romp_bev_postprocess': (C.c_int, [vp, vp, vp, i32, vp, f, f, vp, vp, vp, vp, vp]),
         'romp_project': (C.c_int, [vp, i32, i32, vp, C.POINTER(C.c_float), vp, vp, vp, vp]),
     }
+    # the version first: a stale or mismatched library must fail with THIS message, not with a missing-symbol AttributeError
+    lib.romp_abi_version.restype = C.c_int
+    if lib.romp_abi_version() != ABI_VERSION:
+        raise RompHipError('%s is ABI version %d, this binding needs %d: rebuild it (python -m romp_amd.build --force)'
+                           % (LIB_PATH, lib.romp_abi_version(), ABI_VERSION))
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)      # raises AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.romp_abi_version() != ABI_VERSION:
-        raise RompHipError('libromp_hip.so ABI version mismatch')
+
     _lib = lib
     return lib
 
@@ -125,7 +131,7 @@ EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_f
            'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_set_streams', 'romp_net_profile', 'romp_net_range_scan', 'romp_net_saturated', 'romp_net_set_sat_check', 'romp_net_destroy',
            'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_trace_read', 'romp_conv_describe',
            'romp_net_load', 'romp_net_plan_info', 'romp_net_plan_kind', 'romp_net_autotune', 'romp_net_tuned_variant', 'romp_net_set_tuned', 'romp_net_set_split', 'romp_project_verts', 'romp_estimate_translation', 'romp_cam_to_trans', 'romp_bev_project_verts', 'romp_oneeuro_state_floats', 'romp_oneeuro_smooth', 'romp_sim3dr_normals', 'romp_sim3dr_light', 'romp_sim3dr_rasterize', 'romp_bev_workspace_ints', 'romp_bev_parse', 'romp_bev_regress',
-           'romp_net_buffer_ptr', 'romp_parse', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
+           'romp_net_buffer_ptr', 'romp_parse', 'romp_parse_watch', 'romp_net_sat_counter', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
            'romp_project', 'romp_preprocess', 'romp_preprocess_batch', 'romp_bev_postprocess']
 
 

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import lib as L
-from .net import RompNet
+from .net import RangeGuard, RompNet
 from .post_parser import (_HAVE_CV2, CenterMap, SMPL_parser, body_mesh_projection2image, convert_cam_to_3d_trans, pnp_translation,
                           parsing_outputs)
 from .vis import rendering_romp_bev_results, setup_renderer
@@ -96,6 +96,7 @@ class ROMP(nn.Module):
                                  'there is no CPU fallback' % self.settings.GPU)
         self.tdevice = determine_device(self.settings.GPU)
         self._build_model_(state_dict)
+        self.range_guard = RangeGuard(self.model)          # default-on: no call returns clamped f16x2 maps (net.RangeGuard)
         self._initilization_(smpl_model)
 
     def _build_model_(self, state_dict=None):
@@ -157,8 +158,19 @@ class ROMP(nn.Module):
         else:                                                              # uint8 upload + pad/resize on the device
             input_image, image_pad_info = img_preprocess_device(image, self.tdevice)
         center_maps, params_maps = self.model(input_image)
-        parsed_results = parsing_outputs(center_maps, params_maps, self.centermap_parser)
+        parsed_results, rerun = parsing_outputs(center_maps, params_maps, self.centermap_parser, guard=self.range_guard, quiet=True)
+        if rerun:                                                          # a value left the f16x2 range: the float32 program's answer
+            center_maps, params_maps = self._rerun_f32(input_image)
+            parsed_results = parsing_outputs(center_maps, params_maps, self.centermap_parser)
         return parsed_results, image_pad_info
+
+    def _rerun_f32(self, images):
+        """The call again on the exact-f32 program of the same weights (RompNet.f32_twin) after the range guard tripped; warns
+        once, naming the ops that clamped.  -> (center_maps (B,1,64,64), params_maps (B,64,64,145) NHWC)."""
+        net32 = self.model.f32_twin()
+        center, params = net32.forward_nhwc(images)
+        self.range_guard.warn(images)
+        return center.unsqueeze(1), params
 
     def temporal_optimization(self, outputs, signal_ID):
         """main.py:117-157: OneEuro smoothing of thetas / betas / cam, per tracked person (or of the largest
@@ -205,16 +217,27 @@ class ROMP(nn.Module):
         post-processing issued between them while the GPU idles.  Here everything is enqueued for all `max_person` candidate
         rows while the network is still running -- parse without its count read-back, SMPL, projection, camera translation --
         then ONE small download (count + per-person rows) and one for the N meshes.  Same kernels on the same inputs as the
-        standard path: the same bytes (tests/test_gpu_parity.py::test_romp_api_fast_path)."""
+        standard path: the same bytes (tests/test_gpu_parity.py::test_romp_api_fast_path).  The saturation counter of the network
+        rides in that same download (romp_parse_watch); if it moved, the frame is done again from the float32 program's maps."""
+        x, pad = img_preprocess_device(image, self.tdevice)
+        center, params = self.model.forward_nhwc(x)
+        result, seen = self._fast_from_maps(center, params, pad, self.range_guard.watch)
+        if self.range_guard.check(seen):
+            c32, p32 = self._rerun_f32(x)
+            result, _ = self._fast_from_maps(c32.squeeze(1), p32, pad, None)
+        if result is None:
+            print('None person detected')
+        return result
+
+    def _fast_from_maps(self, center, params, pad, watch):
+        """The latency-arranged post-processing of one frame's maps -> (result dict or None, the watched word or None)."""
         import ctypes as C
         import numpy as np
         from . import lib as L
         lib, dev, cap = L.load(), self.tdevice, self.centermap_parser.max_person
-        x, pad = img_preprocess_device(image, dev)
-        center, params = self.model.forward_nhwc(x)
         st = getattr(self, '_fast', None)
         if st is None:
-            st = self._fast = dict(ibuf=torch.zeros(cap * 4 + 2 * cap + 2, device=dev, dtype=torch.int32),
+            st = self._fast = dict(ibuf=torch.zeros(cap * 4 + 2 * cap + 2 + 2, device=dev, dtype=torch.int32),
                                    fbuf=torch.zeros(cap * (1 + 145 + 3 + 72 + 10), device=dev, dtype=torch.float32))
         ibuf, fbuf = st['ibuf'], st['fbuf']
         views, at = {}, 0
@@ -222,10 +245,10 @@ class ROMP(nn.Module):
             views[key] = fbuf[at:at + cap * w].view(cap, w)
             at += cap * w
         with torch.cuda.device(dev):
-            L.check(lib.romp_parse(L.ptr(center), L.ptr(params), 1, float(self.centermap_parser.conf_thresh), cap, None,
-                                   L.ptr(ibuf), L.ptr(ibuf[cap:]), L.ptr(views['scores']), L.ptr(views['params_pred']), L.ptr(views['cam']),
-                                   L.ptr(views['smpl_thetas']), L.ptr(views['smpl_betas']), L.ptr(ibuf[2 * cap:]), L.ptr(ibuf[4 * cap:]),
-                                   L.stream_ptr(dev)))
+            L.check(lib.romp_parse_watch(L.ptr(center), L.ptr(params), 1, float(self.centermap_parser.conf_thresh), cap, None,
+                                         L.ptr(ibuf), L.ptr(ibuf[cap:]), L.ptr(views['scores']), L.ptr(views['params_pred']), L.ptr(views['cam']),
+                                         L.ptr(views['smpl_thetas']), L.ptr(views['smpl_betas']), L.ptr(ibuf[2 * cap:]), L.ptr(ibuf[4 * cap:]),
+                                         L.stream_ptr(dev), C.c_void_p(watch or 0), None))
         verts, joints, _ = self.smpl_parser.smpl_model(views['smpl_betas'], views['smpl_thetas'], root_align=self.settings.root_align)
         proj = body_mesh_projection2image(joints, views['cam'], input2org_offsets=pad, host_pnp=False)
         small = torch.cat([ibuf.view(torch.float32), fbuf, proj['cam_trans'].reshape(-1), joints.reshape(-1), proj['pj2d_org'].reshape(-1),
@@ -233,9 +256,9 @@ class ROMP(nn.Module):
         host = small.cpu().numpy()                                   # the one synchronisation point of the frame
         hi = host[:ibuf.numel()].view(np.int32)
         N = int(hi[4 * cap + 2 * cap])
+        seen = int(hi[4 * cap + 2 * cap + 2]) if watch else None     # workspace[B * (2 * cap + 2)] with B = 1: the watched word
         if N == 0:
-            print('None person detected')
-            return None
+            return None, seen
         hf = host[ibuf.numel():]
         out, at = {}, 0
         for key, w in (('scores', 1), ('params_pred', 145), ('cam', 3), ('smpl_thetas', 72), ('smpl_betas', 10), ('cam_trans', 3),
@@ -250,7 +273,7 @@ class ROMP(nn.Module):
         return {'cam': out['cam'], 'global_orient': np.ascontiguousarray(th[:, :3]), 'body_pose': np.ascontiguousarray(th[:, 3:]),
                 'smpl_betas': out['smpl_betas'], 'smpl_thetas': th, 'center_preds': hi[2 * cap:4 * cap].reshape(cap, 2)[:N].astype(np.int64),
                 'center_confs': out['scores'].reshape(N, 1), 'cam_trans': out['cam_trans'], 'verts': verts[:N].cpu().numpy(),
-                'joints': out['joints'].reshape(N, 71, 3), 'pj2d_org': out['pj2d_org'].reshape(N, 71, 2)}
+                'joints': out['joints'].reshape(N, 71, 3), 'pj2d_org': out['pj2d_org'].reshape(N, 71, 2)}, seen
 
     def forward(self, image, signal_ID=0, **kwargs):
         """main.py:160-176: BGR uint8 HxWx3 numpy -> dict of numpy arrays, or None."""
@@ -276,7 +299,11 @@ class ROMP(nn.Module):
         tensors (verts (N,6890,3), joints (N,71,3), cam, smpl_thetas, smpl_betas, ...), or
         (None, None) if nobody is detected."""
         center, params = self.model.forward_nhwc(images)
-        outputs, batch_ids = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True)
+        outputs, batch_ids, rerun = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True,
+                                                    guard=self.range_guard, quiet=True)
+        if rerun:                                                          # (the range guard: this call again on the float32 program)
+            c32, p32 = self._rerun_f32(images)
+            outputs, batch_ids = parsing_outputs(c32, p32, self.centermap_parser, return_batch_ids=True)
         if outputs is None:
             return None, None
         outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])
@@ -338,7 +365,15 @@ class ROMP(nn.Module):
             if i + 1 < len(starts):
                 pending = launch(i + 1)
             cur.wait_event(P['ev_net'][i & 1])
-            outputs, batch_ids = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True)
+            # (range guard: the next chunk's network is already running and bumps the same counter -- a change is charged to this
+            # chunk AND the next, RangeGuard.check(next_in_flight=True))
+            self.range_guard.pipelined = i + 1 < len(starts)
+            outputs, batch_ids, rerun = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True,
+                                                        guard=self.range_guard, quiet=True)
+            self.range_guard.pipelined = False
+            if rerun:
+                c32, p32 = self._rerun_f32(images[c0:c0 + chunk])
+                outputs, batch_ids = parsing_outputs(c32, p32, self.centermap_parser, return_batch_ids=True)
             if outputs is not None:
                 outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])
                 if self.settings.calc_smpl:

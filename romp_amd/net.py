@@ -15,6 +15,74 @@ from .plan import Program, build_romp_hrnet32, coord_channels, decode_h2, encode
 
 
 _CHECK_FINITE = os.environ.get('ROMP_CHECK_FINITE', '0') not in ('', '0')
+# The range guard (RangeGuard below) is ON by default.  ROMP_RANGE_GUARD exists for measuring what it costs, not as a product option:
+# '0' = no guard (the round-5 behaviour: clamped maps pass silently), 'nofused' = guard without the counting builds of the two
+# register-resident fused BasicBlock kernels (their clamps then go unseen).
+_RANGE_GUARD = os.environ.get('ROMP_RANGE_GUARD', '1')
+
+
+class RangeGuard:
+    """Default-on range safety of the f16x2 arithmetic.  The reference's network is float32 and has no range to leave
+    (simple_romp/romp/main.py:106-115); the f16x2 kernels clamp a value beyond 65504 / 2^act_shift while splitting it into fp16
+    pieces -- finite, wrong -- and calibration (RompNet._measure_ranges) can only vouch for the frames it saw.  Every clamp bumps
+    the net's device counter (conv_common.h sat_report; the fused BasicBlock kernels in their counting builds, which the guard
+    switches on).  The API reads that counter back WITH the detection count of every call (romp_parse_watch: the same D2H, the
+    same synchronisation -- no extra round trip) and hands it to `check`; a change means this call clamped somewhere, and the
+    caller re-runs it on the exact-f32 program of the same weights (`RompNet.f32_twin`, built on first need) -- so no call of the
+    API returns clamped maps.  Pipelined callers (ROMP.forward_chunks) have the NEXT network already in flight when they read the
+    counter: a change is then charged to this call AND the next (`carry`), which is conservative and cannot miss one."""
+
+    def __init__(self, net):
+        self.net = net
+        self.enabled = bool(net.bf16x3) and _RANGE_GUARD != '0'
+        self.seen, self.carry, self.reruns, self.warned = 0, False, 0, False
+        if self.enabled:
+            if _RANGE_GUARD != 'nofused':
+                net.set_sat_check(True)
+            self.seen = net.saturated & 0xffffffff
+
+    @property
+    def watch(self):
+        """Device address of the counter for romp_parse_watch (None: guard off)."""
+        return self.net.sat_counter if self.enabled else None
+
+    def check(self, value, next_in_flight=False):
+        """`value`: the counter as it came back with this call's counts (None: guard off).  True: re-run this call in float32."""
+        if not self.enabled or value is None:
+            return False
+        value &= 0xffffffff
+        changed = value != self.seen
+        hit = changed or self.carry
+        self.carry = changed and next_in_flight
+        self.seen = value
+        if hit:
+            self.reruns += 1
+        return hit
+
+    def resync(self):
+        """After anything else bumped the counter (a range scan): take its present value as seen."""
+        if self.enabled:
+            self.seen = self.net.saturated & 0xffffffff
+
+    def warn(self, images=None):
+        """Once per net: say that a forward left the calibrated range, and (given the frames) which ops clamped."""
+        if self.warned:
+            return
+        self.warned = True
+        import warnings
+        ops = ''
+        if images is not None:
+            try:
+                torch.cuda.synchronize(self.net.device)        # (a pipelined caller has another forward of this net in flight: the scan uses the same arena)
+                scan = self.net.range_scan(images[:min(int(images.shape[0]), 2)])
+                names = [nm for nm, _, _, sat in scan if sat > 0]
+                ops = '; clamping ops: ' + (', '.join(names[:8]) + (' ... (%d in all)' % len(names) if len(names) > 8 else '') if names else 'none on the first frames')
+                self.resync()
+            except L.RompHipError:
+                pass
+        warnings.warn('romp_amd: activations left the calibrated range of the f16x2 kernels (values beyond 65504 / 2^act_shift were clamped); '
+                      'the call was re-run on the exact-f32 program and its result is the float32 one.  Calibrate on representative '
+                      'frames (--calib_dir / calib_images=) or use --conv_math f32 to avoid the second forward' + ops)
 
 
 class RompNet:
@@ -48,6 +116,7 @@ class RompNet:
             if builder is None:
                 builder = build_romp_hrnet32
             self.program: Program = builder(state_dict, self.device, input_size, bf16x3=bf16x3, **kw)
+            self._src = (state_dict, builder, kw, out_shapes)        # what f32_twin() lowers again (references, no copies)
             if calibrate is None:
                 calibrate = bool(getattr(self.program, 'f16x2', False))
             self.op_maxabs = None
@@ -139,7 +208,7 @@ class RompNet:
             t.set_graph(getattr(self, '_use_graph', False))
             return t
         t = RompNet.__new__(RompNet)
-        for k in ('device', 'lib', 'max_batch', 'bf16x3', 'split', 'split_k', 'input_size', 'program', 'op_maxabs', 'range_fallback', 'out_shapes'):
+        for k in ('device', 'lib', 'max_batch', 'bf16x3', 'split', 'split_k', 'input_size', 'program', 'op_maxabs', 'range_fallback', 'out_shapes', '_src'):
             setattr(t, k, getattr(self, k, None))
         t._tuned = set()
         with torch.cuda.device(self.device):
@@ -162,6 +231,32 @@ class RompNet:
             t.set_streams(False)
         return t
 
+    def f32_twin(self):
+        """The exact-f32 lowering of the same weights (conv_math='f32': v_mfma_f32_32x32x2_f32 products, float32 tensors -- no
+        fp16 range anywhere), built on first need and kept: what RangeGuard re-runs a call on whose activations left the
+        calibrated range.  A net loaded from a plan file holds only its own packed constants and cannot build one."""
+        t = getattr(self, '_f32', None)
+        if t is not None:
+            return t
+        src = getattr(self, '_src', None)
+        if src is None:
+            raise L.RompHipError('activations left the calibrated range of the f16x2 kernels and this net was loaded from a plan file, which '
+                                 'holds no float32 program to fall back to: export the plan with conv_math=f32 or calibrated on '
+                                 'representative frames (python -m romp_amd.export --calib_dir), or start from --model_path')
+        state_dict, builder, kw, out_shapes = src
+        t = RompNet(state_dict, self.device, max_batch=self.max_batch, input_size=self.input_size, builder=builder, out_shapes=out_shapes,
+                    bf16x3='f32', split_k=self.split_k, calibrate=False)
+        if not getattr(self, '_use_streams', True):
+            t.set_streams(False)
+        t.set_graph(getattr(self, '_use_graph', False))
+        self._f32 = t
+        return t
+
+    @property
+    def sat_counter(self):
+        """Device address of the saturation counter (romp_net_sat_counter): the `watch` argument of romp_parse_watch."""
+        return int(self.lib.romp_net_sat_counter(self._h) or 0)
+
     @classmethod
     def from_plan(cls, path, device, max_batch=32, use_graph=False, out_shapes=None):
         """A net from a plan file (export.save_plan): no state_dict, no lowering -- libromp_hip.so's romp_net_load does it all.
@@ -175,7 +270,7 @@ class RompNet:
         self.lib = L.load()
         self.max_batch = int(max_batch)
         plan = read_plan(path)
-        self._plan_path = path
+        self._plan_path, self._src = path, None
         ops = plan['ops']
         self.bf16x3 = any(o.weight_h2 or o.weight_aux for o in ops)
         self.split, self.split_k, self.input_size = 1, plan['split_k_items'], plan['input_size']     # (the plan KIND is in the header)

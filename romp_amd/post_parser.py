@@ -26,7 +26,7 @@ class CenterMap(object):
     def parse_centermap(self, center_maps, params_maps_nhwc=None):
         """post_parser.py:27-47.  Returns batch_ids, flat_inds, center_yxs, scores (device tensors).
         Order: batch-major, score-descending inside an image (ties: lower flat index)."""
-        r = _parse(center_maps, params_maps_nhwc, self.conf_thresh, self.max_person)
+        r, _ = _parse(center_maps, params_maps_nhwc, self.conf_thresh, self.max_person)
         if r is None:
             e = torch.empty(0, device=center_maps.device)
             return e.long(), e.long(), e.reshape(0, 2), e
@@ -34,7 +34,9 @@ class CenterMap(object):
         return r['batch_ids'], r['flat_inds'], yx, r['scores']
 
 
-def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person):
+def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person, watch=None):
+    """-> (dict of row tensors or None, watched word or None).  `watch`: device address of an int32 that rides back with the
+    counts (romp_parse_watch; RompNet.sat_counter for the API's range guard)."""
     lib = L.load()
     dev = center_maps.device
     if dev.type != 'cuda':
@@ -47,7 +49,7 @@ def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person):
     assert pm.shape == (B, 64, 64, 145) and pm.dtype == torch.float32
     cap = B * max_person
     # one allocation per dtype, sliced: the single-image path pays for every torch.empty
-    ibuf = torch.empty(cap * 4 + B * (2 * max_person + 2), device=dev, dtype=torch.int32)
+    ibuf = torch.empty(cap * 4 + B * (2 * max_person + 2) + 2, device=dev, dtype=torch.int32)
     fbuf = torch.empty(cap * (1 + 145 + 3 + 72 + 10), device=dev, dtype=torch.float32)
     out, at = {}, 0
     for key, w in (('scores', 1), ('params_pred', 145), ('cam', 3), ('smpl_thetas', 72), ('smpl_betas', 10)):
@@ -56,30 +58,42 @@ def _parse(center_maps, params_maps_nhwc, conf_thresh, max_person):
     out['batch_ids'], out['flat_inds'] = ibuf[:cap], ibuf[cap:2 * cap]
     out['center_preds'] = ibuf[2 * cap:4 * cap].view(cap, 2)
     ws = ibuf[4 * cap:]
-    n = C.c_int32(0)
+    n, w = C.c_int32(0), C.c_int32(0)
     with torch.cuda.device(dev):
-        L.check(lib.romp_parse(L.ptr(cm), L.ptr(pm), B, float(conf_thresh), int(max_person), C.byref(n),
-                               L.ptr(out['batch_ids']), L.ptr(out['flat_inds']), L.ptr(out['scores']),
-                               L.ptr(out['params_pred']), L.ptr(out['cam']), L.ptr(out['smpl_thetas']),
-                               L.ptr(out['smpl_betas']), L.ptr(out['center_preds']), L.ptr(ws), L.stream_ptr(dev)))
+        L.check(lib.romp_parse_watch(L.ptr(cm), L.ptr(pm), B, float(conf_thresh), int(max_person), C.byref(n),
+                                     L.ptr(out['batch_ids']), L.ptr(out['flat_inds']), L.ptr(out['scores']),
+                                     L.ptr(out['params_pred']), L.ptr(out['cam']), L.ptr(out['smpl_thetas']),
+                                     L.ptr(out['smpl_betas']), L.ptr(out['center_preds']), L.ptr(ws), L.stream_ptr(dev),
+                                     C.c_void_p(watch or 0), C.byref(w)))
     N = n.value
+    seen = w.value if watch else None
     if N == 0:
-        return None
+        return None, seen
     out = {k: v[:N] for k, v in out.items()}
     il = ibuf[:4 * cap].long()                                # the reference's index tensors are int64: one cast for the three
     out['batch_ids'], out['flat_inds'], out['center_preds'] = il[:N], il[cap:cap + N], il[2 * cap:4 * cap].view(cap, 2)[:N]
-    return out
+    return out, seen
 
 
-def parsing_outputs(center_maps, params_maps, centermap_parser, return_batch_ids=False):
+def parsing_outputs(center_maps, params_maps, centermap_parser, return_batch_ids=False, guard=None, quiet=False):
     """post_parser.py:135-146 (+ the 1.1**scale of main.py:113, which the kernel applies to the
     sampled rows only).  center_maps (B,1,64,64); params_maps either the NHWC tensor
     (B,64,64,145) produced by RompNet.forward_nhwc or a (B,145,64,64) NCHW(-view) tensor.
-    Returns the reference's dict (device tensors) or None when nobody is detected."""
+    Returns the reference's dict (device tensors) or None when nobody is detected.
+    `guard` (net.RangeGuard of the net that produced the maps): its saturation counter comes back with the detection count and
+    the result has a third / second element: True when the caller must re-run this call in float32 (`quiet`: no 'None person
+    detected' line for a result that is about to be replaced)."""
     if params_maps.dim() == 4 and params_maps.shape[1] == 145 and params_maps.shape[-1] != 145:
         params_maps = params_maps.permute(0, 2, 3, 1)          # free for RompNet's NCHW view
-    r = _parse(center_maps, params_maps, centermap_parser.conf_thresh, centermap_parser.max_person)
-    if r is None:
+    r, seen = _parse(center_maps, params_maps, centermap_parser.conf_thresh, centermap_parser.max_person,
+                     watch=guard.watch if guard is not None else None)
+    if guard is not None:
+        rerun = guard.check(seen, next_in_flight=getattr(guard, 'pipelined', False))
+        if r is None:
+            if not (rerun and quiet):
+                print('None person detected')
+            return (None, None, rerun) if return_batch_ids else (None, rerun)
+    elif r is None:
         print('None person detected')
         return (None, None) if return_batch_ids else None
     thetas = r['smpl_thetas']
@@ -88,6 +102,8 @@ def parsing_outputs(center_maps, params_maps, centermap_parser, return_batch_ids
         'smpl_betas': r['smpl_betas'], 'smpl_thetas': thetas,
         'center_preds': r['center_preds'], 'center_confs': r['scores'].unsqueeze(1),
     }
+    if guard is not None:
+        return (res, r['batch_ids'], rerun) if return_batch_ids else (res, rerun)
     return (res, r['batch_ids']) if return_batch_ids else res
 
 

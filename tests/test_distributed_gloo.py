@@ -158,8 +158,8 @@ def _bench_worker(rank, world, port, q):
     lo, hi = D.shard_range(G, rank, world)
     images = torch.zeros(hi - lo, 2, 2, 3)
     images[:, 0, 0, 0] = torch.arange(lo, hi).float()
-    dt, persons = bench.run_job(args, _StubModel(), images, lo, rank, world, dev, D)
-    res = bench.headline_result(args, dt, persons, G, hi - lo, world, dev, 'stub')
+    dt, persons, timing = bench.run_job(args, _StubModel(), images, lo, rank, world, dev, D)
+    res = bench.headline_result(args, dt, persons, G, hi - lo, world, dev, 'stub', timing)
     q.put((rank, res, persons, dt))
     dist.barrier()
     dist.destroy_process_group()
@@ -189,6 +189,10 @@ def test_bench_job_loop_world2():
         assert line['config']['global_batch'] == 22 and line['config']['images_per_gpu_per_step'] == 11
         assert abs(line['value'] - 22 * 3 / dt) < 0.01 * line['value']
         assert abs(line['config']['persons_per_image'] - round(want_persons / 22, 2)) < 1e-9
+        # the line says what it was taken under: one duration per timed step (exactly --steps of them), the un-counted pre-heat
+        assert len(line['step_ms']['all']) == 3 and line['step_ms']['min'] <= line['step_ms']['median'] <= line['step_ms']['max']
+        assert 2 <= len(line['preheat_step_ms']) <= 40 and line['preheat_s'] > 0
+    assert len({len(r[1]['preheat_step_ms']) for r in res}) == 1, 'every rank must take the same pre-heat decision'
 
 
 def test_bench_respawns_itself_for_multi_gpu(monkeypatch):
