@@ -579,7 +579,7 @@ class GpuSensors:
         import glob
         import threading
         self.period, self.samples, self._stop, self._thread = period, [], threading.Event(), None
-        self.index, self.source, self._files = device_index, None, None
+        self.index, self.source, self._files, self.static = device_index, None, None, {}
         try:
             pr = torch.cuda.get_device_properties(device_index)
             bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
@@ -590,6 +590,11 @@ class GpuSensors:
                 if os.path.exists(fr) and self._read(fr) is not None:
                     self._files = (fr, pw[0] if pw and self._read(pw[0]) is not None else None)
                     self.source = 'sysfs hwmon (%s)' % bdf
+                    # read once, outside the sampling loop: memory clock, hottest sensor, the power cap the job runs into
+                    mc, cap = self._read(os.path.join(hw[0], 'freq2_input')), self._read(os.path.join(hw[0], 'power1_cap'))
+                    temps = [self._read(f) for f in glob.glob(os.path.join(hw[0], 'temp*_input'))]
+                    self.static = {'mclk_mhz': None if mc is None else round(mc / 1e6), 'power_cap_w': None if cap is None else round(cap / 1e6),
+                                   'temp_c_at_start': max([t / 1e3 for t in temps if t is not None], default=None)}
         except Exception:                              # noqa: BLE001 -- a sensor is optional
             self._files = None
         if self._files is None:
@@ -644,6 +649,7 @@ class GpuSensors:
 
     def summary(self):
         out = {'clock_mhz': None, 'power_w': None, 'sensor_source': self.source, 'sensor_samples': len(self.samples)}
+        out.update(self.static)
         for key, col in (('clock_mhz', 0), ('power_w', 1)):
             v = sorted(s[col] for s in self.samples if s[col] is not None)
             if v:

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libromp_hip.so')
 # (heaviest translation units first: the thread pool below starts them in this order and the link waits for the slowest)
 SOURCES = ['conv_h2.hip', 'conv_h2c.hip', 'conv_h2c32.hip', 'conv_f32.hip', 'conv_h2d.hip', 'conv_bx3.hip', 'conv_h2b.hip', 'conv_h2r.hip',
-           'conv_h2s.hip', 'conv_mfma.hip', 'conv_h2k.hip', 'conv_h2x.hip', 'conv_fup.hip', 'stem_fuse.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip',
+           'conv_h2s.hip', 'conv_mfma.hip', 'conv_h2k.hip', 'conv_h2g.hip', 'conv_h2x.hip', 'conv_fup.hip', 'stem_fuse.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip',
            'post.hip', 'render.hip', 'temporal.hip']
 # the fused-block kernels' tile loop is ONE fully unrolled body (270 MFMAs with a step of side work after each): beyond the default budget of `#pragma unroll`
 _UNROLL = ['-mllvm', '-pragma-unroll-threshold=1000000']

@@ -45,7 +45,7 @@ struct XCfg {
 
 typedef float f32x4x __attribute__((ext_vector_type(4)));
 
-template <int DS>
+template <int DS, int DRAIN = 0>
 __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
     using X = XCfg;
     using frag = f16x8;
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
         // ---- the next m (x0) has landed (see the header): everything older than the operations issued after the DMAs has completed.
         // Barrier: every wave's share of it is there, t may be overwritten
         static_assert(X::after_dma(0) == 52 && X::after_dma(1) == 20, "the counted waits below");
-        if (DS) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+        // (DRAIN = 1: the full drain of round 3 -- its own instantiation, chosen by ROMP_CONV_DEBUG=1024, so that a GPU test can compare
+        // the counted waits bit for bit against it; a RUN-TIME switch here made hipcc spill the DS = 1 tile loop)
+        if (DRAIN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (DS) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(52) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         mb ^= 1;
@@ -287,6 +290,8 @@ int launch_seam1x1(const romp_op& opa, const romp_op& opb, const romp_op* opd, c
     if (!attr) {
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(0)));
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(1)));
+        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(0)));
+        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(seam1x1_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, XCfg::lds_bytes(1)));
         int dev = 0;
         hipDeviceProp_t prop;
         ROMP_HIP_CHECK(hipGetDevice(&dev));
@@ -304,6 +309,7 @@ int launch_seam1x1(const romp_op& opa, const romp_op& opb, const romp_op* opd, c
     p.scale_h = opb.scale_h2; p.shift = opb.shift;
     p.act_scale = ldexpf(1.f, opa.act_shift);
     p.sat = conv_sat_counter();
+    { const char* e = getenv("ROMP_CONV_DEBUG"); p.dbg = e ? (atoi(e) & 1024) : 0; }      // 1024: the full-drain builds (tests)
     {
         const unsigned long long bytes = ((unsigned long long)B * opa.H * opa.W * opa.in_cstride - opa.in_coff) * 4ull;
         ROMP_REQUIRE(bytes < 0x80000000ull, "seam1x1: input tensor of %llu bytes: beyond the 31-bit offsets of the DMA", bytes);
@@ -324,7 +330,10 @@ int launch_seam1x1(const romp_op& opa, const romp_op& opb, const romp_op* opd, c
     p.tiles_total = (int)(((long)B * opa.H * opa.W) / XCfg::N);
     long grid = num_cu;
     if (grid > p.tiles_total) grid = p.tiles_total;
-    if (opd) hipLaunchKernelGGL(seam1x1_kernel<1>, dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(1), st, p);
+    if (p.dbg & 1024) {
+        if (opd) hipLaunchKernelGGL((seam1x1_kernel<1, 1>), dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(1), st, p);
+        else hipLaunchKernelGGL((seam1x1_kernel<0, 1>), dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(0), st, p);
+    } else if (opd) hipLaunchKernelGGL(seam1x1_kernel<1>, dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(1), st, p);
     else hipLaunchKernelGGL(seam1x1_kernel<0>, dim3((unsigned)grid), dim3(256), XCfg::lds_bytes(0), st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;

@@ -49,6 +49,7 @@ static void collect_variants() {
     t = conv_variants_h2r(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2s(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2k(&n); kVariants.insert(kVariants.end(), t, t + n);
+    t = conv_variants_h2g(&n); kVariants.insert(kVariants.end(), t, t + n);      // (appended last: the indices of older variants do not move)
     kNumVariants = (int)kVariants.size();
 }
 static bool g_attr_done = false;
@@ -271,7 +272,7 @@ int describe_conv(const romp_op& op, int B, int variant, char* out, int n) {
     if (variant < 0) variant = choose_variant(op, Ho, Wo, B);
     ROMP_REQUIRE(variant >= 0 && variant < kNumVariants, "describe: no variant");
     const ConvVariant& v = kVariants[variant];
-    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 10 ? "conv_h2k" : v.math == 9 ? "conv_h2s" : v.math == 8 ? "conv_h2r" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
+    snprintf(out, n, "%s_k%ds%d_mt%d_nt%d_tw%d_ck%d", v.math == 11 ? "conv_h2g" : v.math == 10 ? "conv_h2k" : v.math == 9 ? "conv_h2s" : v.math == 8 ? "conv_h2r" : v.math == 4 ? (v.o4 ? "conv_h2do" : "conv_h2d") : v.math == 3 ? (v.o4 ? "conv_h2o" : "conv_h2") : v.math == 2 ? "conv_bxd" : v.math ? "conv_bx3" : (v.pp ? "conv_pp" : "conv_mfma"), v.ks, v.s, v.mt, v.nt,
              v.tw, v.ck);
     return ROMP_OK;
 }

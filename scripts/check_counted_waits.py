@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'romp_amd', 'csrc')
 FILES = {'h2x': ('conv_h2x.hip', []), 'h2c': ('conv_h2c.hip', ['-mllvm', '-pragma-unroll-threshold=1000000']),
          'h2c32': ('conv_h2c32.hip', ['-mllvm', '-pragma-unroll-threshold=1000000'])}
-EXPECT = {'seam1x1_kernelILi0E': (52, 'loop'), 'seam1x1_kernelILi1E': (20, 'loop'),
+EXPECT = {'seam1x1_kernelILi0ELi0E': (52, 'loop'), 'seam1x1_kernelILi1ELi0E': (20, 'loop'),
           'bblockr_kernelILi64ELi0E': (6, 'layout'), 'bblockr_kernelILi32ELi0E': (3, 'layout'),
           'bblockr_kernelILi64ELi16E': (6, 'layout'), 'bblockr_kernelILi32ELi16E': (3, 'layout')}
 VMEM = re.compile(r'^\s*(global_load|global_store|buffer_load|buffer_store|global_atomic|buffer_atomic|flat_load|flat_store|scratch_)')
@@ -104,7 +104,7 @@ def main(which):
                 if name.endswith(tag + 'EEvNS_10ConvParamsE'):
                     for n_wait, younger in check(name, body, n, mode):
                         found += 1
-                        ok = younger >= n_wait if mode == 'loop' else younger == n_wait
+                        ok = younger == n_wait       # exactly: a duplicated / peeled path would raise the static count of the loop above the issue count of one path
                         bad += not ok
                         print('%-62s vmcnt(%d): %d vector-memory instructions younger than the DMA  %s' % (name[:62], n_wait, younger, 'ok' if ok else 'NOT COVERED'))
                     break

@@ -12,6 +12,10 @@ CASES = {
     's2': [(32, 64, 3, 2, 128, False), (64, 128, 3, 2, 64, False), (128, 256, 3, 2, 32, False), (64, 64, 3, 2, 256, False),
            (32, 128, 3, 2, 128, False), (32, 96, 3, 2, 128, False), (64, 192, 3, 2, 64, False), (256, 64, 3, 2, 128, False), (48, 192, 3, 2, 128, False)],
     'k1': [(64, 256, 1, 1, 128, False), (256, 64, 1, 1, 128, True), (64, 64, 1, 1, 128, False)],
+    # ResNet-50 layers 2-4 (resnet_50.py:64-78): conv1 4C -> C, conv3 C -> 4C + residual, the strided downsample
+    'rn': [(256, 128, 1, 1, 128, False), (128, 512, 1, 1, 64, True), (512, 128, 1, 1, 64, False), (256, 512, 1, 2, 128, False),
+           (256, 1024, 1, 1, 32, True), (1024, 256, 1, 1, 32, False), (512, 1024, 1, 2, 64, False),
+           (512, 2048, 1, 1, 16, True), (2048, 512, 1, 1, 16, False), (1024, 2048, 1, 2, 32, False)],
 }
 
 
@@ -40,6 +44,8 @@ def run_case(case, B, filt, check):
     out = torch.empty(B, Ho, Ho, cout, device=dev)
     buf = C.create_string_buffer(128)
     flops = 2.0 * B * Ho * Ho * cout * cin * k * k
+    # algorithmic bytes: every input pixel the conv uses once, the output (and residual) once, the weights once
+    abytes = 4.0 * (B * (Ho * Ho * cin * (1 if k == 1 else s * s) + Ho * Ho * cout * (2 if use_res else 1)) + cin * cout * k * k)
     st = torch.cuda.current_stream().cuda_stream
     rows, ref = [], None
     for v in range(lib.romp_conv_num_variants()):
@@ -68,7 +74,7 @@ def run_case(case, B, filt, check):
             L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), L.ptr(rd), L.ptr(out), B, 0, v, st))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        rows.append((name, v, ms * 1e3, flops / ms / 1e9, err))
+        rows.append((name, v, ms * 1e3, flops / ms / 1e9, '%6.0f GB/s  %s' % (abytes / ms / 1e6, err)))
     return rows
 
 

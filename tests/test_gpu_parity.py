@@ -167,6 +167,12 @@ CONV_CASES = [
     (64, 32, 1, 1, 64, False, False), (128, 32, 1, 1, 32, False, False), (256, 128, 1, 1, 16, False, False),
     (128, 96, 1, 1, 32, False, False), (256, 224, 1, 1, 16, False, False),     # merged up-convs (conv_h2k at B = 1)
     (64, 142, 1, 1, 64, False, False), (64, 1, 1, 1, 64, False, False), (64, 3, 1, 1, 64, False, False),
+    # ResNet-50's Bottleneck 1x1 convs, layers 2-4 (resnet_50.py:64-78: C -> 4C + residual, 4C -> C, the strided downsample):
+    # the shapes csrc/conv_h2g.hip was written for (K streamed in 64-channel stages)
+    (256, 128, 1, 1, 64, True, False), (128, 512, 1, 1, 64, True, True), (512, 128, 1, 1, 64, True, False), (256, 512, 1, 2, 128, False, False),
+    (256, 1024, 1, 1, 32, True, True), (1024, 256, 1, 1, 32, True, False), (512, 1024, 1, 2, 64, False, False),
+    (512, 2048, 1, 1, 16, True, True), (2048, 512, 1, 1, 16, True, False), (1024, 2048, 1, 2, 32, False, False),
+    (96, 64, 1, 1, 32, True, False), (64, 64, 1, 2, 64, True, False),          # 32-channel stages; a small strided 1x1
 ]
 
 
@@ -1278,3 +1284,59 @@ def test_seam1x1_downsample(dev, B, H, monkeypatch):
     for name in ('t', 'u'):                                      # the two lowerings agree to float32 rounding (the fold adds in float32 what
         d = (outs[('1', name)] - outs[('0', name)]).abs().max().item()      # the separate launch rounds to two fp16 pieces first)
         assert d < 2e-5 * max(1.0, outs[('0', name)].abs().max().item()), (name, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ds', ['1', '0'])
+def test_seam1x1_counted_waits_vs_full_drain(dev, ds, monkeypatch):
+    """the seam kernel ends a tile on a COUNTED wait (vmcnt(52) / vmcnt(20)) that lets stores and the next residual stay in
+    flight across the barrier; if the compiled loop ever issued fewer memory operations behind the DMA than the count, the barrier
+    would release before the next m tile has landed -- a silent LDS race.  scripts/check_counted_waits.py counts the compiled
+    instructions (CPU test); here the same programs run with the full-drain instantiation (ROMP_CONV_DEBUG=1024: vmcnt(0), round 3's
+    form) and must give bit-identical tensors, eight tiles deep per workgroup."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math
+    monkeypatch.setenv('ROMP_FUSE_SEAMS', '1')
+    monkeypatch.setenv('ROMP_SEAM_DS', ds)
+    B, H = 8, 128
+    g = torch.Generator().manual_seed(97)
+    img = torch.randn(B, H, H, 64, generator=g)
+    dims = [(64, 64), (64, 64), (64, 256), (64, 256), (256, 64), (64, 64)]
+    ws = [torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5 for ci, co in dims]
+    sc = [torch.rand(co, generator=g) + 0.5 for _, co in dims]
+    sh = [torch.randn(co, generator=g) * 0.2 for _, co in dims]
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    a0 = P.conv('x0', Act(L.BUF_IMAGE, 64, H, H, 64), [ws[0]], [sc[0]], [sh[0]], 1, 1, True)
+    am = P.conv('m', a0, [ws[1]], [sc[1]], [sh[1]], 1, 1, True)
+    ad = P.conv('d', a0, [ws[2]], [sc[2]], [sh[2]], 1, 1, False)
+    at = P.conv('t', am, [ws[3]], [sc[3]], [sh[3]], 1, 1, True, res=ad)
+    au = P.conv('u', at, [ws[4]], [sc[4]], [sh[4]], 1, 1, True)
+    P.conv('v', au, [ws[5]], [sc[5]], [sh[5]], 1, 1, True)
+    ops = P.op_array()
+    assert P.fused_seams == 1 and getattr(P, 'folded_downsamples', 0) == (1 if ds == '1' else 0)
+    lib = L.load()
+    h = C.c_void_p()
+    sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+    L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+    got = {}
+    try:
+        xd = img.to(dev).contiguous()
+        dummy = torch.empty(16, device=dev)
+        for dbg in ('0', '1024', '0'):
+            monkeypatch.setenv('ROMP_CONV_DEBUG', dbg)
+            for rep in range(3):
+                L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+                for act, name in ((at, 't'), (au, 'u')):
+                    n = P.buf_floats[act.buf] * B
+                    out = torch.empty(n, device=dev)
+                    L.check(lib.romp_net_read_buffer(h, act.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
+                    torch.cuda.synchronize()
+                    bits = out.view(torch.int32).cpu()
+                    if name in got:
+                        assert torch.equal(bits, got[name]), 'seam ds=%s, ROMP_CONV_DEBUG=%s, pass %d: tensor %s differs from the first run' % (ds, dbg, rep, name)
+                    else:
+                        got[name] = bits
+    finally:
+        lib.romp_net_destroy(h)

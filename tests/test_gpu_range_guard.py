@@ -139,7 +139,12 @@ def test_api_single_frame_blown_up_net(dev):
         for got in (fast, std):
             assert np.array_equal(got['center_preds'], ref['center_preds'])
             for k in ('cam', 'smpl_thetas', 'verts', 'joints', 'pj2d_org'):
-                assert np.abs(got[k] - ref[k]).max() <= 1e-5 * max(1.0, np.abs(ref[k]).max()), k
+                # (maps 3e4 x their usual size: 1.1 ** scale overflows float32 in the reference arithmetic itself -- the same
+                # non-finite entries on both sides, everything finite within 1e-5)
+                fin = np.isfinite(ref[k])
+                assert np.array_equal(fin, np.isfinite(got[k])), k
+                if fin.any():
+                    assert np.abs(got[k][fin] - ref[k][fin]).max() <= 1e-5 * max(1.0, np.abs(ref[k][fin]).max()), k
 
 
 def test_plan_file_net_fails_loudly_instead_of_returning_clamped_maps(dev, tmp_path):
