@@ -75,6 +75,10 @@ def parse_args():
     ap.add_argument('--no-f32-companion', action='store_true', help='skip the extra conv_math=f32 timing of the same workload')
     ap.add_argument('--no-latency', action='store_true', help='skip the single-image ROMP(settings)(frame) latency leg')
     ap.add_argument('--with-verts', type=int, default=0, help='N>1: also all-gather the 6890x3 vertices')
+    ap.add_argument('--cross-step', type=int, default=1,
+                    help='1: keep the chunk pipeline primed across steps (the next step\'s first network is launched under this step\'s last '
+                         'parse + SMPL + all-gather) and the record exchange at a fixed capacity (counts inside the one all-gather); 0: every '
+                         'step fills and drains its own pipeline (rounds 1-5)')
     ap.add_argument('--preheat-cap', type=float, default=10.0,
                     help='seconds: UNcounted pre-heat steps in front of --warmup until two consecutive steps agree within 1 %% '
                          '(a fresh box runs its first steps slowly); 0: none.  The timed region stays exactly --steps steps')
@@ -769,16 +773,25 @@ def run_job(args, model, images, lo, rank, world, dev, D, sensors=None):
     timing record: per-step times, the pre-heat's steps)."""
     B = args.batch
     persons = [0]
+    # steady state of a stream of identical jobs (round 6): the shard is walked again next step, so the chunk pipeline stays primed
+    # across steps (the next step's first network under this step's last parse + SMPL + all-gather) and the record exchange keeps
+    # its capacity (counts inside the one all-gather).  Every step still launches exactly its own number of networks.
+    nxt = images if getattr(args, 'cross_step', 1) else None
+    gather_state = {} if getattr(args, 'cross_step', 1) else None
 
     def step():
         if world > 1:
-            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts), chunk=B)
+            out, counts = D.sharded_forward(model, images, lo, with_joints=True, with_verts=bool(args.with_verts), chunk=B, next_images=nxt,
+                                            gather_state=gather_state)
             persons[0] = sum(counts)
         else:
-            rec = D.local_records(model, images, lo, chunk=B, with_joints=True, with_verts=bool(args.with_verts))
+            rec = D.local_records(model, images, lo, chunk=B, with_joints=True, with_verts=bool(args.with_verts), next_images=nxt)
             persons[0] = 0 if rec is None else rec.shape[0]
     pre_s, pre_ms = preheat(step, dev, world, cap_s=getattr(args, 'preheat_cap', 10.0)) if getattr(args, 'preheat_cap', 10.0) > 0 else (0.0, [])
     dt, per = timed_steps(step, args.warmup, args.steps, dev, world, sensors)
+    pipe = getattr(model, '_pipe', None)
+    if pipe is not None:
+        pipe['primed'] = None            # (the last step announced a step that will not come: timed_steps has synchronised, nothing is in flight)
     timing = {'preheat_s': round(pre_s, 3), 'preheat_step_ms': [round(x, 3) for x in pre_ms],
               'step_ms': step_stats(per.get('gpu', per['host'])), 'step_ms_clock': 'HIP events on the launch stream' if 'gpu' in per else 'host',
               'step_ms_host': step_stats(per['host'])}
@@ -800,7 +813,7 @@ def headline_result(args, dt, persons, G, n_local, world, dev, variant_table, ti
            'ms_per_call': round(dt / args.steps / max(1, -(-n_local // B)) * 1e3, 3),
            'persons_per_image': round(persons / G, 2), 'center_thresh': args.center_thresh, 'hipgraph': bool(args.graph),
            'autotune': bool(args.autotune), 'variant_table': variant_table, 'branch_streams': bool(args.streams),
-           'conv_math': args.conv_math, 'parallelism': 'dp%d' % world}
+           'conv_math': args.conv_math, 'parallelism': 'dp%d' % world, 'cross_step_pipeline': bool(getattr(args, 'cross_step', 1))}
     cfg.update(collective_info(world, dev))
     res = {
         'metric': 'images/sec (512x512, %s)' % bb, 'value': round(G * args.steps / dt, 2), 'unit': 'images/s',

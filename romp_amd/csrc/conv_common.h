@@ -74,6 +74,19 @@ __device__ __forceinline__ void sat_track(float& mx, float a, float b) { mx = __
 __device__ __forceinline__ void sat_report(int* counter, float mx) {
     if (counter && __builtin_amdgcn_ballot_w64(mx >= H2_MAX) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1);
 }
+// The packed form for POST-ReLU values (non-negative; round 6): the running per-half maximum of the HIGH-piece dwords a kernel has
+// just formed -- v_pk_maximum3_f16, new in gfx950: ONE instruction per two dwords = four values (the float32 form above is one per
+// two; the fused BasicBlock kernels' counting builds used one per value and cost 1.7-2 % of the job, profiles/r06_guard_cost.txt).
+// A half reads 0x7BFF (65504) iff its value was clamped, 0x7E00 if it was a NaN: either is reported.
+__device__ __forceinline__ unsigned sat_track_pk(unsigned mx, unsigned h0, unsigned h1) {
+    unsigned d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(mx), "v"(h0), "v"(h1));
+    return d;
+}
+__device__ __forceinline__ void sat_report_pk(int* counter, unsigned mx) {
+    const bool hit = (mx & 0x7fffu) >= 0x7bffu || ((mx >> 16) & 0x7fffu) >= 0x7bffu;
+    if (counter && __builtin_amdgcn_ballot_w64(hit) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1);
+}
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // fp16x2 of (a - hi.x, b - hi.y): the low pieces of two values whose packed high pieces are `hi`.  ONE asm block (v_fma_mix_f32 takes an
 // fp16 operand as it is; hipcc turns `x - (float)h` into a convert and a subtract, and follows every single-instruction asm whose result

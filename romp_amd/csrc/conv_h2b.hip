@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     // a VALU instruction 4) and one step follows each MFMA, pinned there with a scheduling barrier.
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
     f32x16 acc2[2];                                            // (block 1's outlives its tile: finished under the next tile's conv1)
-    float sat_mx = 0.f;                                        // (DBG & 16, the checked build) largest value handed to a split: == H2_MAX iff clamped
+    unsigned sat_pk = 0u;                                      // (DBG & 16, the checked build) per-half maximum of the high pieces formed: 0x7BFF iff clamped (sat_track_pk)
     Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
@@ -258,12 +258,14 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
                 const int e = w == 1 ? 0 : w == 3 ? 1 : w == 7 ? 2 : 3;
                 const unsigned wh = e < 2 ? e_rh.x : e_rh.y, wl = e < 2 ? e_rl.x : e_rl.y;
                 ev[e] = (e & 1) ? add_pieces_relu<1>(ev[e], wh, wl, H2_MAX) : add_pieces_relu<0>(ev[e], wh, wl, H2_MAX);
-                if ((DBG & 16) && live) sat_mx = fmaxf(sat_mx, ev[e]);      // (not live: the first tile's pass over a block that does not exist)
                 if (w == 9 && g4 < 3) prep(g4 + 1);            // the tables are free: the next group's reads go out now
                 break; }
             case 4: split_a(ev[0], ev[1], eh[0]); break;
             case 5: split_b(ev[0], ev[1], eh[0], el[0]); break;
-            case 10: split_a(ev[2], ev[3], eh[1]); break;
+            case 10:
+                split_a(ev[2], ev[3], eh[1]);
+                if ((DBG & 16) && live) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);      // (not live: the first tile's pass over a block that does not exist)
+                break;
             case 11: split_b(ev[2], ev[3], eh[1], el[1]); break;
             case 12: {
                 // lanes L (channels .. + 0..3) and L + 32 (.. + 4..7): after the swaps L holds the octet's 8 high pieces, L + 32 its 8 low
@@ -330,13 +332,15 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             case 0: case 1: case 4: case 5: {
                 const int e = w < 2 ? w : w - 2;
                 const float a = h2_sat(fmaxf(fmaf(acc1[sl][g4 * 4 + e], h_sc[e], h_sh[e]), 0.f));
-                if ((DBG & 16) && h_in) sat_mx = fmaxf(sat_mx, a);
                 hv[e] = h_in ? a : 0.f;
                 if (w == 5 && g4 < 3) prep(g4 + 1);            // the tables are free: the next group's reads go out now
                 break; }
             case 2: split_a(hv[0], hv[1], hh[0]); break;
             case 3: split_b(hv[0], hv[1], hh[0], ll[0]); break;
-            case 6: split_a(hv[2], hv[3], hh[1]); break;
+            case 6:
+                split_a(hv[2], hv[3], hh[1]);
+                if (DBG & 16) sat_pk = sat_track_pk(sat_pk, hh[0], hh[1]);       // (pixels outside the image are zeros)
+                break;
             case 7: split_b(hv[2], hv[3], hh[1], ll[1]); break;
             case 8: if (act) *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 0) * 16) = make_uint2(hh[0], hh[1]); break;
             default: if (act) *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 1) * 16) = make_uint2(ll[0], ll[1]); break;
@@ -464,9 +468,9 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) ev[e] = fmaxf(fmaf(acc2[1][g4 * 4 + e], e_sc[e], e_sh[e]) + ((float)rh[e] + (float)rl[e]), 0.f);
             unsigned eh[2], el[2];
-            if (DBG & 16) { sat_track(sat_mx, ev[0], ev[1]); sat_track(sat_mx, ev[2], ev[3]); }
             split2(ev[0], ev[1], eh[0], el[0]);
             split2(ev[2], ev[3], eh[1], el[1]);
+            if (DBG & 16) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);
             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
             const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(eh[0], el[0], false, false);
             const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(eh[1], el[1], false, false);
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             *reinterpret_cast<uint4*>(o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
     }
-    if (DBG & 16) sat_report(p.sat, sat_mx);
+    if (DBG & 16) sat_report_pk(p.sat, sat_pk);
 #undef SIDE_PIN
 }
 

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
 
     f32x4c acc2[X::THW];                                        // (the last row's outlives its tile: finished under the next tile's first MFMAs)
-    float sat_mx = 0.f;                                         // (DBG & 16) largest value handed to a split: == H2_MAX iff clamped
+    unsigned sat_pk = 0u;                                       // (DBG & 16) per-half maximum of the high pieces formed: a half == 0x7BFF iff a value was clamped (conv_common.h sat_track_pk)
     Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
@@ -217,9 +217,11 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
                 const unsigned wh = e < 2 ? e_rh.x : e_rh.y, wl = e < 2 ? e_rl.x : e_rl.y;
                 const float v = fmaf(acc2[r][e], s2[e], b2[e]);
                 ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
-                if ((DBG & 16) && live) sat_mx = fmaxf(sat_mx, ev[e]);      // (not live: the first tile's pass over a row that does not exist)
                 break; }
-            case 5: eh[0] = pack_hi(ev[0], ev[1]); eh[1] = pack_hi(ev[2], ev[3]); break;
+            case 5:
+                eh[0] = pack_hi(ev[0], ev[1]); eh[1] = pack_hi(ev[2], ev[3]);
+                if ((DBG & 16) && live) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);      // (not live: the first tile's pass over a row that does not exist)
+                break;
             case 6: el[0] = h2_low_pair(eh[0], ev[0], ev[1]); el[1] = h2_low_pair(eh[1], ev[2], ev[3]); break;
             case 7: {
                 // lanes (px, q even) and (px, q odd) hold channels .. + 0..3 and .. + 4..7 of an octet: after the swaps the even one
@@ -257,11 +259,13 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #pragma unroll
                 for (int e = 2 * t; e < 2 * t + 2; ++e) {
                     const float v = h2_sat(fmaxf(fmaf(a[e], s1[e], b1[e]), 0.f));
-                    if ((DBG & 16) && inside) sat_mx = fmaxf(sat_mx, v);
                     hv[e] = inside ? v : 0.f;
                 }
                 break; }
-            case 2: hh[0] = pack_hi(hv[0], hv[1]); hh[1] = pack_hi(hv[2], hv[3]); break;
+            case 2:
+                hh[0] = pack_hi(hv[0], hv[1]); hh[1] = pack_hi(hv[2], hv[3]);
+                if (DBG & 16) sat_pk = sat_track_pk(sat_pk, hh[0], hh[1]);       // (pixels outside the image are zeros)
+                break;
             case 3: hl[0] = h2_low_pair(hh[0], hv[0], hv[1]); hl[1] = h2_low_pair(hh[1], hv[2], hv[3]); break;
             case 4: if (act) *reinterpret_cast<uint2*>(sBuf + addr) = make_uint2(hh[0], hh[1]); break;
             default: if (act) *reinterpret_cast<uint2*>(sBuf + addr + X::MPL * 16) = make_uint2(hl[0], hl[1]); break;
@@ -473,9 +477,9 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
             const unsigned wh = e < 2 ? rh.x : rh.y, wl = e < 2 ? rl.x : rl.y;
             const float v = fmaf(acc2[r][e], s2[e], b2[e]);
             ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
-            if (DBG & 16) sat_mx = fmaxf(sat_mx, ev[e]);
         }
         unsigned eh[2] = {pack_hi(ev[0], ev[1]), pack_hi(ev[2], ev[3])};
+        if (DBG & 16) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);
         unsigned el[2] = {h2_low_pair(eh[0], ev[0], ev[1]), h2_low_pair(eh[1], ev[2], ev[3])};
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t a = __builtin_amdgcn_permlane16_swap(eh[0], el[0], false, false);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
         float* o = p.out + (size_t)itp.b * p.out_bs + p.out_co + (unsigned)((oy * p.out_rs + ox * p.out_cs) + (16 * cg + 4 * q));
         *reinterpret_cast<uint4*>(o) = make_uint4(a[0], b[0], a[1], b[1]);
     }
-    if (DBG & 16) sat_report(p.sat, sat_mx);
+    if (DBG & 16) sat_report_pk(p.sat, sat_pk);
 #undef SIDE_PIN
 }
 

@@ -27,11 +27,12 @@
 
 namespace romp {
 
-template <int P, int NS, int TW, int S, int KSUB>
+template <int KS, int P, int NS, int TW, int S, int KSUB>
 struct GCfg {
     static constexpr int NWV = 4;
+    static constexpr int TAPS = KS * KS;                       // KS = 2: one output parity of a ConvTranspose2d(k4, s2, p1) (resnet_plan.py): K = 4 taps x Cin
     static constexpr int PG = NWV / NS;                        // pixel groups (waves along the pixel dimension)
-    using C = ConvCfg<1, S, P, NS, TW, 16, PG>;                // TH = PG * P * (32 / TW) output rows, NW = NS * 32 channels
+    using C = ConvCfg<KS, S, P, NS, TW, 16, PG>;               // TH = PG * P * (32 / TW) output rows, NW = NS * 32 channels
     static constexpr int NPIX = PG * P * 32;                   // output pixels of a tile
     static constexpr int NI = NPIX / 8 / NWV;                  // DMA pieces (8 pixels x 128 bytes) per wave and 32-channel sub-stage
     static constexpr int SUB_BYTES = NPIX * 128;               // one 32-channel sub-stage
@@ -46,6 +47,7 @@ struct GCfg {
     static constexpr int PFU = 2;                              // fragment reads run PFU units ahead of their MFMAs
     static constexpr int PPE = KSUB * NI / NCH;                // DMA pieces issued per chunk end (= NI / 2)
     static_assert(NS == 1 || NS == 2 || NS == 4, "channel slices per workgroup");
+    static_assert(KS == 1 || (KS == 2 && S == 1), "1x1 (stride 1 / 2) or the 2x2 parity conv");
     static_assert(NPIX % 32 == 0 && NI >= 2 && NI % 2 == 0, "the same number of whole pieces at every chunk end");
     static_assert((KSUB - 1) * SUB_BYTES + (P - 1) * 4096 < 65536, "fragment read offsets are ds_read immediates");
 };
@@ -55,15 +57,16 @@ typedef const __attribute__((address_space(1))) void glb_void_g;
 
 struct GStage {                 // wave-uniform description of one stage's sources
     const float* in;            // image + group + first channel of the stage
-    const uint4* wg;            // group + chunk + this wave's channel slice of the split weights
+    const uint4* wg;            // group + tap + chunk + this wave's channel slice of the split weights
     int oy0, ox0;               // output tile origin
+    int dy, dx;                 // input pixel of output pixel (oy, ox): (oy * S + dy, ox * S + dx)  (1x1: 0, 0; 2x2: tap - padding)
     int c0;
 };
 
-template <int P, int NS, int TW, int S, int KSUB>
+template <int KS, int P, int NS, int TW, int S, int KSUB>
 __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
     if (p.dbg & 32) return;                            // ablation: launch cost only
-    using X = GCfg<P, NS, TW, S, KSUB>;
+    using X = GCfg<KS, P, NS, TW, S, KSUB>;
     using C = typename X::C;
     using frag = f16x8;
     constexpr int NWV = X::NWV, PG = X::PG, G = X::G, PFU = X::PFU, NCH = X::NCH;
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
     const int sl = wave % NS, pg = wave / NS;                  // channel slice, pixel group
     const int li = lane & 31, lh = lane >> 5;
     const int q = p.n_queues == 8 ? (blockIdx.x & 7) : 0;
-    const int n_stages = p.cin_pad / (32 * KSUB);
+    const int spt = p.cin_pad / (32 * KSUB);                   // stages per tap
+    const int n_stages = X::TAPS * spt;                        // stage st = tap st / spt, channels (st % spt) * 32 * KSUB ..: the packed weights' own order
     const int cin16 = p.cin_pad >> 4;
     char* sE = sBuf + X::OFF_E + wave * EPI_WAVE;
 
@@ -97,12 +101,15 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
     }
     const int cold = (p.dbg & 1) ? 0 : 1;                      // ablation bit 1: every DMA piece reads the zero page (no HBM traffic)
 
-    auto make_desc = [&](const Item& it, int c0) {
+    auto make_desc = [&](const Item& it, int st) {
         GStage d;
+        const int tap = KS == 1 ? 0 : st / spt, c0 = (KS == 1 ? st : st % spt) * (32 * KSUB);
         d.in = p.in + (size_t)it.b * p.H * p.W * p.in_cs + p.in_co + it.g * p.in_gs + c0;
-        d.wg = p.wh + (size_t)it.g * (cin16 * 4 * p.cout_pad) + (c0 >> 4) * 4 * p.cout_pad + it.n0 + sl * 32;
+        d.wg = p.wh + (size_t)it.g * (X::TAPS * cin16 * 4 * p.cout_pad) + (size_t)st * (2 * KSUB * 4) * p.cout_pad + it.n0 + sl * 32;
         d.oy0 = it.ty * C::TH;
         d.ox0 = it.tx * TW;
+        d.dy = KS == 1 ? 0 : tap / KS - p.pad_h;
+        d.dx = KS == 1 ? 0 : tap % KS - p.pad_w;
         d.c0 = c0;
         return d;
     };
@@ -113,8 +120,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
         asm volatile("" : "+v"(rc));                                       // (opaque: keeps the per-piece address parts from being hoisted into VGPRs)
         const int row = rc & 255, col = (rc >> 8) & 255, w = (rc >> 17) & 7;
         const int oy = d.oy0 + row, ox = d.ox0 + col;
-        const int ok = (int)(oy < p.Ho) & (int)(d.c0 + sub * 32 + (w >> 1) * 8 < p.cin_valid) & cold;
-        const unsigned long long a_in = (unsigned long long)(d.in + ((oy * S * p.W + ox * S) * p.in_cs + sub * 32 + w * 4));
+        const int iy = oy * S + d.dy, ix = ox * S + d.dx;
+        int ok = (int)(oy < p.Ho) & (int)(d.c0 + sub * 32 + (w >> 1) * 8 < p.cin_valid) & cold;
+        if (KS != 1) ok &= (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);      // (the taps' zero padding)
+        const unsigned long long a_in = (unsigned long long)(d.in + ((iy * p.W + ix) * p.in_cs + sub * 32 + w * 4));
         const unsigned long long a = ok ? a_in : (unsigned long long)p.zero;
         __builtin_amdgcn_global_load_lds((glb_void_g*)a, (lds_void_g*)(sBuf + buf * X::STAGE_BYTES + sub * X::SUB_BYTES + i * 1024), 16, 0, 0);
     };
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
     while (true) {
         const bool last = ch + 1 == n_stages;
         // the stage to prefetch; a workgroup's final stage re-fetches itself (harmless, keeps the stage body branch-free)
-        const GStage nd = make_desc(last ? (have_next ? nxt : cur) : cur, last ? (have_next ? 0 : ch * 32 * KSUB) : (ch + 1) * 32 * KSUB);
+        const GStage nd = make_desc(last ? (have_next ? nxt : cur) : cur, last ? (have_next ? 0 : ch) : ch + 1);
         const int nbuf = buf ^ 1;
         ROMP_TRACE(10);
         if (!(p.dbg & 8)) {
@@ -228,6 +237,12 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
         ROMP_TRACE(11);
         if (last) {
             if (have_next) issue_ss(nxt, slot ^ 1);
+#ifndef ROMP_H2G_DRAIN_LATE
+            // The next stage's DMA pieces and weights (issued inside the stage body above) are waited for HERE, in front of the epilogue:
+            // the item then ends on a barrier alone and its output stores stay in flight into the next item (the HBM-bound layers
+            // are 2-8 stages per item: a full drain behind the epilogue exposed one store round trip per item)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if (!(p.dbg & 4)) {
                 Item ce = cur;
                 ce.n0 += sl * 32;
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));
                 const float* sc_e = reinterpret_cast<const float*>(sSb + slot * X::SS_BYTES) + sl * 64;
-                if (p.out_h2 && p.vec_io && (!p.res || p.res_h2) && !(p.dbg & 512)) conv_epilogue_h2direct<1, S, P, TW, PG>(p, ce, acc, sc_e, pg, lane_e & 31, lane_e >> 5);
+                if (p.out_h2 && p.vec_io && (!p.res || p.res_h2) && !(p.dbg & 512)) conv_epilogue_h2direct<KS, S, P, TW, PG>(p, ce, acc, sc_e, pg, lane_e & 31, lane_e >> 5);
                 else {
                     char* se = sE;
                     if (X::EPI_ALIAS) {                            // (a workgroup-uniform branch: every wave meets at this barrier)
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
                         __builtin_amdgcn_s_barrier();
                         se = sBuf + buf * X::STAGE_BYTES + wave * EPI_WAVE;
                     }
-                    conv_epilogue<1, S, P, 1, TW, 16, PG>(p, ce, acc, sc_e, se, pg, lane_e & 31, lane_e >> 5);
+                    conv_epilogue<KS, S, P, 1, TW, 16, PG>(p, ce, acc, sc_e, se, pg, lane_e & 31, lane_e >> 5);
                 }
             }
 #pragma unroll
@@ -268,24 +283,31 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
         buf ^= 1;
         // this wave's DMA pieces of the next stage have landed (and its weight registers); every wave is done reading the buffer
         // the stage after next will overwrite
+#ifndef ROMP_H2G_DRAIN_LATE
+        if (ch == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (an item's last stage: drained in front of its epilogue)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_s_barrier();
         ROMP_TRACE(12);
     }
 }
 
-#define ROMP_CONV_VARIANT_H2G(P, NS, TW, S, KSUB)                                                         \
-    { 1, S, P, NS, TW, 32 * KSUB, conv_h2g_kernel<P, NS, TW, S, KSUB>, GCfg<P, NS, TW, S, KSUB>::LDS_BYTES, \
-      GCfg<P, NS, TW, S, KSUB>::C::TH, 0, 0, 11, 256 }
+#define ROMP_CONV_VARIANT_H2G(KS, P, NS, TW, S, KSUB)                                                                \
+    { KS, S, P, NS, TW, 32 * KSUB, conv_h2g_kernel<KS, P, NS, TW, S, KSUB>, GCfg<KS, P, NS, TW, S, KSUB>::LDS_BYTES, \
+      GCfg<KS, P, NS, TW, S, KSUB>::C::TH, 0, 0, 11, 256 }
 
 static ConvVariant kVariantsH2g[] = {
     // 128 pixels x 128 channels, 64 x 128, 256 x 64, 128 x 64 (64-channel outputs: layer1's conv1, HRNet's transition-free 1x1s)
-    ROMP_CONV_VARIANT_H2G(4, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(4, 4, 32, 1, 2), ROMP_CONV_VARIANT_H2G(2, 4, 16, 1, 2),
-    ROMP_CONV_VARIANT_H2G(4, 2, 16, 1, 1), ROMP_CONV_VARIANT_H2G(2, 2, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 1, 16, 1, 2),
+    ROMP_CONV_VARIANT_H2G(1, 4, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(1, 4, 4, 32, 1, 2), ROMP_CONV_VARIANT_H2G(1, 2, 4, 16, 1, 2),
+    ROMP_CONV_VARIANT_H2G(1, 4, 2, 16, 1, 1), ROMP_CONV_VARIANT_H2G(1, 2, 2, 16, 1, 2), ROMP_CONV_VARIANT_H2G(1, 2, 1, 16, 1, 2),
     // 32-channel stages (Cin = 32 / 96 / 160 ..: not a multiple of 64)
-    ROMP_CONV_VARIANT_H2G(2, 4, 16, 1, 1), ROMP_CONV_VARIANT_H2G(2, 2, 16, 1, 1), ROMP_CONV_VARIANT_H2G(2, 1, 16, 1, 1),
+    ROMP_CONV_VARIANT_H2G(1, 2, 4, 16, 1, 1), ROMP_CONV_VARIANT_H2G(1, 2, 2, 16, 1, 1), ROMP_CONV_VARIANT_H2G(1, 2, 1, 16, 1, 1),
     // the strided `downsample` convs (resnet_50.py:64-78)
-    ROMP_CONV_VARIANT_H2G(4, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(2, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(2, 2, 16, 2, 2),
+    ROMP_CONV_VARIANT_H2G(1, 4, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(1, 2, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(1, 2, 2, 16, 2, 2),
+    // the 2x2 parity convs of the three ConvTranspose2d(k4, s2, p1) layers (resnet_50.py:80-120): K = 4 taps x Cin, matrix-bound
+    ROMP_CONV_VARIANT_H2G(2, 4, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 2, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 2, 2, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 4, 2, 16, 1, 1),
 };
 ConvVariant* conv_variants_h2g(int* n) { *n = (int)(sizeof(kVariantsH2g) / sizeof(kVariantsH2g[0])); return kVariantsH2g; }
 

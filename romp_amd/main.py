@@ -315,11 +315,16 @@ class ROMP(nn.Module):
 
 
     @torch.no_grad()
-    def forward_chunks(self, images, chunk):
+    def forward_chunks(self, images, chunk, next_images=None):
         """[extension] forward_batch over `images` (n,512,512,3) in chunks of `chunk` images, software-pipelined: the network of
         chunk i+1 (its own HIP stream and its own pair of output maps) runs while chunk i is parsed and meshed on the caller's
         stream, so the host sync of the parse (the detection count) and the parse / SMPL kernels hide under the next network
-        forward.  Yields (outputs dict or None, batch_ids or None, first image index of the chunk)."""
+        forward.  Yields (outputs dict or None, batch_ids or None, first image index of the chunk).
+        `next_images` (round 6): the tensor the NEXT call of forward_chunks will walk (same chunk size; it must stay alive and
+        unchanged until then).  The pipeline then stays primed across calls: the network of the next call's first chunk is
+        launched under this call's last parse + SMPL (and whatever the caller does between the calls -- packing records, the
+        all-gather), and the next call picks it up instead of starting with an exposed network.  A job of few chunks per call (the
+        8-GPU shard: 4 calls of 32 per step) otherwise fills and drains the pipeline every step."""
         dev = self.tdevice
         n = images.shape[0]
         starts = list(range(0, n, chunk))
@@ -334,7 +339,7 @@ class ROMP(nn.Module):
             nets = [self.model, self.model.twin()] if two else [self.model, self.model]
             streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if two else [torch.cuda.Stream(dev)] * 2
             self._pipe = dict(nets=nets, streams=streams, bufs={}, ev_net=[torch.cuda.Event(), torch.cuda.Event()],
-                              ev_free=[torch.cuda.Event(), torch.cuda.Event()])
+                              ev_free=[torch.cuda.Event(), torch.cuda.Event()], primed=None)
         P = self._pipe
         cur = torch.cuda.current_stream(dev)
 
@@ -345,29 +350,39 @@ class ROMP(nn.Module):
                                   torch.empty((B,) + tuple(self.model.out_shapes[1]), device=dev))
             return P['bufs'][key]
 
-        def launch(i):
-            x = images[starts[i]:starts[i] + chunk]
-            c, p_ = bufs(x.shape[0], i & 1)
-            st = P['streams'][i & 1]
-            st.wait_event(P['ev_free'][i & 1])                    # the chunk that used this pair of maps has been parsed
+        def launch(x, par):
+            c, p_ = bufs(x.shape[0], par)
+            st = P['streams'][par]
+            st.wait_event(P['ev_free'][par])                      # the chunk that used this pair of maps has been parsed
             with torch.cuda.stream(st):
-                P['nets'][i & 1].forward_nhwc(x, c, p_)
-                P['ev_net'][i & 1].record(st)
+                P['nets'][par].forward_nhwc(x, c, p_)
+                P['ev_net'][par].record(st)
             return c, p_
 
-        P['ev_free'][0].record(cur)
-        P['ev_free'][1].record(cur)
-        for st in set(P['streams']):
-            st.wait_stream(cur)                                   # the images are ready
-        pending = launch(0)
+        # a first chunk launched by the previous call (its `next_images` were these images)?  Its parity decides this call's
+        primed, P['primed'] = P['primed'], None
+        if primed is not None and (primed['ptr'], primed['shape'], primed['chunk']) == (images.data_ptr(), tuple(images.shape), chunk):
+            off, pending = primed['par'], primed['bufs']
+        else:
+            off = 0
+            P['ev_free'][0].record(cur)
+            P['ev_free'][1].record(cur)
+            for st in set(P['streams']):
+                st.wait_stream(cur)                               # the images are ready
+            pending = launch(images[starts[0]:starts[0] + chunk], off)
         for i, c0 in enumerate(starts):
             center, params = pending
-            if i + 1 < len(starts):
-                pending = launch(i + 1)
-            cur.wait_event(P['ev_net'][i & 1])
+            par = (i + off) & 1
+            more = i + 1 < len(starts)
+            if more:
+                pending = launch(images[starts[i + 1]:starts[i + 1] + chunk], par ^ 1)
+            elif next_images is not None and next_images.shape[0] > 0:
+                P['primed'] = dict(ptr=next_images.data_ptr(), shape=tuple(next_images.shape), chunk=chunk, par=par ^ 1,
+                                   bufs=launch(next_images[:chunk], par ^ 1))
+            cur.wait_event(P['ev_net'][par])
             # (range guard: the next chunk's network is already running and bumps the same counter -- a change is charged to this
             # chunk AND the next, RangeGuard.check(next_in_flight=True))
-            self.range_guard.pipelined = i + 1 < len(starts)
+            self.range_guard.pipelined = more or P['primed'] is not None
             outputs, batch_ids, rerun = parsing_outputs(center.unsqueeze(1), params, self.centermap_parser, return_batch_ids=True,
                                                         guard=self.range_guard, quiet=True)
             self.range_guard.pipelined = False
@@ -378,10 +393,11 @@ class ROMP(nn.Module):
                 outputs['cam_trans'] = convert_cam_to_3d_trans(outputs['cam'])
                 if self.settings.calc_smpl:
                     outputs = self.smpl_parser(outputs, root_align=self.settings.root_align)
-            P['ev_free'][i & 1].record(cur)
+            P['ev_free'][par].record(cur)
             yield outputs, batch_ids, c0
-        for st in set(P['streams']):
-            cur.wait_stream(st)
+        if P['primed'] is None:                                   # (primed: the caller's stream must NOT wait for the next call's network)
+            for st in set(P['streams']):
+                cur.wait_stream(st)
 
 
 def _imread_bgr(path):

@@ -496,6 +496,18 @@ def stream_races(P):
         return r, w
 
     ordered = lambda i, j: at[j][1][at[i][0]] >= i           # op i happens-before op j (i earlier in op order)
+
+    def interleaved(i, j):
+        """Two convs that write DIFFERENT parities of one tensor through the same sparse output strides (the four 2x2 parity convs
+        of a transposed conv, resnet_plan.py: out_cstride = two pixels, out_rstride = two rows, out_coff = a rows + b pixels) touch
+        disjoint elements of the buffer: not a write-write conflict."""
+        a, b = ops[i], ops[j]
+        if not (a.kind == OP_CONV and b.kind == OP_CONV and a.out_rstride > 0 and a.Cout * 2 <= a.out_cstride and
+                (a.out_rstride, a.out_bstride, a.out_cstride, a.Cout) == (b.out_rstride, b.out_bstride, b.out_cstride, b.Cout)):
+            return False
+        par = lambda o: (o.out_coff // (o.out_rstride // 2), (o.out_coff % (o.out_rstride // 2)) // (o.out_cstride // 2))
+        return par(a) != par(b)
+
     last_w, readers, races = {}, {}, []
     for j in range(len(ops)):
         if at[j] is None:
@@ -508,7 +520,7 @@ def stream_races(P):
             readers.setdefault(b, []).append(j)
         for b in w:
             i = last_w.get(b)
-            if i is not None and i != j and not ordered(i, j):
+            if i is not None and i != j and not ordered(i, j) and not interleaved(i, j):
                 races.append(('WAW', b, P.names[i], P.names[j]))
             races += [('WAR', b, P.names[i], P.names[j]) for i in readers.get(b, []) if i != j and not ordered(i, j)]
             last_w[b], readers[b] = j, []

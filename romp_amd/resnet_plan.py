@@ -95,13 +95,18 @@ def build_romp_resnet50(sd, device, input_size=512, bf16x3=False, split_k_items=
             out = Act(P.head_in_buf, co, H2, W2, RESNET_HEAD_CH)
         else:
             out = P.new_act(co, H2, W2)
+        # the four parities are independent and write disjoint (interleaved) elements: one stream each -- a parity conv of the first
+        # layer (2048 -> 256 @16^2) is 128-256 work items on 512 workgroup slots, four of them fill the chip (round 6)
+        P.fork(3)
         for a in range(2):
             for bpar in range(2):
+                P.on(2 * a + bpar)
                 w2 = torch.stack([torch.stack([w[:, :, KY[a][dy], KY[bpar][dx]] for dx in range(2)], -1) for dy in range(2)], -2)
                 w2 = w2.permute(1, 0, 2, 3).contiguous()     # (Cout, Cin, 2, 2)
                 P.conv(f'deconv{d}.p{a}{bpar}', x, [w2], [s], [b], 2, 1, True, out_buf_special=out.buf,
                        out_cstride=2 * out.cstride, out_coff=a * W2 * out.cstride + bpar * out.cstride,
                        pad=(1 - a, 1 - bpar), out_rstride=2 * W2 * out.cstride, out_bstride=H2 * W2 * out.cstride)
+        P.join()
         P.free(x)
         x = out
     head_x = Act(P.head_in_buf, RESNET_HEAD_CH, fs, fs, RESNET_HEAD_CH)

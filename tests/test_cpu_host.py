@@ -301,7 +301,8 @@ def test_resnet50_plan_inventory():
     from oracle import resnet_oracle as RO
     from romp_amd.resnet_plan import build_romp_resnet50
     P = build_romp_resnet50(RO.make_resnet_state_dict(0), 'cpu')
-    assert len(P.ops) == 76      # (+ the fork / join around the three output convs)
+    assert len(P.ops) == 82      # (+ the fork / join around the three output convs and, round 6, around each layer's four parity convs)
+    assert P.names.count('fork') == 4 and sorted({o.stream for n, o in zip(P.names, P.ops) if n.startswith('deconv0')}) == [0, 1, 2, 3]
     assert abs(sum(P.flops) / 1e9 - 53.79) < 0.05      # (the head.conv0 term counts the reference's 66 input channels, not the padded 80)
     dec = [(n, o) for n, o in zip(P.names, P.ops) if n.startswith('deconv')]
     assert len(dec) == 12 and all(o.ksize == 2 and o.stride == 1 and o.out_rstride > 0 and o.out_bstride > 0 for _, o in dec)

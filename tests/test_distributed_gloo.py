@@ -109,6 +109,28 @@ class _StubModel:
         return out, bids
 
 
+class _StubPipelinedModel(_StubModel):
+    """The stub with ROMP.forward_chunks' interface, including the cross-call priming protocol of round 6: `next_images` names the
+    tensor the next call will walk; its first chunk is then taken from the primed slot (here: computed eagerly when it was
+    announced).  `primed_used` counts the calls that started from a primed first chunk."""
+
+    def __init__(self):
+        self.primed, self.primed_used = None, 0
+
+    def forward_chunks(self, images, chunk, next_images=None):
+        starts = list(range(0, images.shape[0], chunk))
+        first = None
+        if self.primed is not None and self.primed[0] == (images.data_ptr(), tuple(images.shape), chunk):
+            first = self.primed[1]
+            self.primed_used += 1
+        self.primed = None
+        for i, c0 in enumerate(starts):
+            out, bids = first if (i == 0 and first is not None) else self.forward_batch(images[c0:c0 + chunk])
+            if i + 1 == len(starts) and next_images is not None:
+                self.primed = ((next_images.data_ptr(), tuple(next_images.shape), chunk), self.forward_batch(next_images[:chunk]))
+            yield out, bids, c0
+
+
 def _chunk_worker(rank, world, port, n_images, chunk, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -160,6 +182,22 @@ def _bench_worker(rank, world, port, q):
     images[:, 0, 0, 0] = torch.arange(lo, hi).float()
     dt, persons, timing = bench.run_job(args, _StubModel(), images, lo, rank, world, dev, D)
     res = bench.headline_result(args, dt, persons, G, hi - lo, world, dev, 'stub', timing)
+    # the cross-step form (round 6: pipeline primed across steps, fixed-capacity record exchange) against the plain one: the same
+    # records, step after step, and the protocol really ran (every step but the first starts from a primed chunk; one counted
+    # exchange, then one all-gather per step)
+    pm = _StubPipelinedModel()
+    state = {}
+    plain, _ = D.sharded_forward(_StubModel(), images, lo, with_joints=True, chunk=args.batch)
+    same = True
+    for _ in range(4):
+        got, counts = D.sharded_forward(pm, images, lo, with_joints=True, chunk=args.batch, next_images=images, gather_state=state)
+        same = same and all(torch.equal(got[k], plain[k]) for k in plain)
+    res['_cross_step'] = dict(same=bool(same), primed_used=pm.primed_used, exchanges=state.get('exchanges', 0), cap=state.get('cap', 0),
+                              regrown=state.get('regrown', 0))
+    # a step with MORE persons than the capacity: every rank regrows together and the result is still complete
+    state['cap'] = 1
+    got, counts = D.sharded_forward(_StubModel(), images, lo, with_joints=True, chunk=args.batch, gather_state=state)
+    res['_cross_step']['regrow_ok'] = bool(all(torch.equal(got[k], plain[k]) for k in plain)) and state['cap'] >= max(counts) and state.get('regrown', 0) == 1
     q.put((rank, res, persons, dt))
     dist.barrier()
     dist.destroy_process_group()
@@ -192,6 +230,9 @@ def test_bench_job_loop_world2():
         # the line says what it was taken under: one duration per timed step (exactly --steps of them), the un-counted pre-heat
         assert len(line['step_ms']['all']) == 3 and line['step_ms']['min'] <= line['step_ms']['median'] <= line['step_ms']['max']
         assert 2 <= len(line['preheat_step_ms']) <= 40 and line['preheat_s'] > 0
+        assert line['config']['cross_step_pipeline'] is True
+        cs = line['_cross_step']
+        assert cs['same'] and cs['primed_used'] == 3 and cs['exchanges'] == 3 and cs['cap'] >= 64 and cs['regrow_ok'], cs
     assert len({len(r[1]['preheat_step_ms']) for r in res}) == 1, 'every rank must take the same pre-heat decision'
 
 

@@ -1144,6 +1144,49 @@ def test_forward_chunks_pipelined_equals_forward_batch(dev, mb, n, monkeypatch):
         s.synchronize()
 
 
+@pytest.mark.parametrize('mb,n', [(2, 5), (2, 8), (4, 8)])
+def test_forward_chunks_primed_across_calls(dev, mb, n):
+    """Round 6: `next_images` keeps the chunk pipeline primed across calls (the next call's first network is launched under this
+    call's last parse + SMPL).  Odd and even chunk counts (the primed chunk's parity carries over), the same tensor walked again
+    and a DIFFERENT tensor announced: every call returns exactly what forward_batch returns; a primed chunk that is never
+    picked up (another tensor arrives) is dropped without harm."""
+    import romp_amd
+    settings = romp_amd.romp_settings([])
+    settings.GPU, settings.center_thresh, settings.max_batch = 0, 1.3, mb
+    sd = O.make_romp_state_dict(0, center_bias=2.0)
+    model = romp_amd.ROMP(settings, state_dict=sd, smpl_model=O.make_synthetic_smpl(0))
+    model.model.set_graph(True)
+    xa, xb = O.make_images(n, seed=9).to(dev), O.make_images(n, seed=10).to(dev)
+    keys = ('cam', 'smpl_thetas', 'smpl_betas', 'verts', 'joints', 'center_preds', 'center_confs')
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        want = {}
+        for name, x in (('a', xa), ('b', xb)):
+            want[name] = []
+            for c0 in range(0, n, mb):
+                out, bids = model.forward_batch(x[c0:c0 + mb])
+                want[name].append(None if out is None else {k: out[k].clone() for k in keys} | {'bids': bids.clone()})
+
+        def check(x, name, nxt):
+            got = list(model.forward_chunks(x, mb, next_images=nxt))
+            for (out, bids, _), w in zip(got, want[name]):
+                assert (out is None) == (w is None)
+                if out is not None:
+                    assert torch.equal(bids, w['bids'])
+                    for k in keys:
+                        assert torch.equal(out[k], w[k]), (name, k)
+        check(xa, 'a', xa)
+        assert model._pipe['primed'] is not None
+        check(xa, 'a', xa)                                       # picked up the primed first chunk
+        check(xa, 'a', xb)                                       # announces the other tensor
+        assert model._pipe['primed']['ptr'] == xb.data_ptr()
+        check(xb, 'b', xa)
+        check(xb, 'b', None)                                     # xa was announced, xb arrives: the primed chunk is dropped
+        assert model._pipe['primed'] is None
+        check(xa, 'a', None)
+        s.synchronize()
+
+
 def test_graph_cache_is_bounded(dev):
     """Graph mode with fresh output tensors on every call: the per-(batch, pointers) hipGraph cache must stay
     bounded (it is dropped and rebuilt past 32 entries) and keep producing the same maps."""

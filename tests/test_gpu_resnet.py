@@ -67,6 +67,50 @@ def test_transposed_conv_as_parity_convs(dev, cin, cout, H):
     print('deconv %d->%d @%d: %d kernel variants, worst max-abs %.2e' % (cin, cout, H, len(worst), max(worst.values())))
 
 
+@pytest.mark.parametrize('cin,cout,H', [(2048, 256, 16), (256, 128, 32), (128, 64, 64)])
+def test_transposed_conv_as_parity_convs_h2(dev, cin, cout, H):
+    """The same four parity convs on pre-split H2 tensors (what the f16x2 program runs): every kernel variant that can take the layer
+    -- the generic f16x2 kernels and csrc/conv_h2g.hip's K = 4 taps x Cin form -- writes its parity of the interleaved H2 output
+    through the sparse output strides; the decoded tensor against torch's ConvTranspose2d."""
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, Act, set_conv_math, encode_h2, decode_h2, ACT_SHIFT
+    B = 2
+    g = torch.Generator().manual_seed(cin + 1)
+    x = torch.randn(B, cin, H, H, generator=g)
+    w = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(F.conv_transpose2d(x, w, None, stride=2, padding=1) * scale[None, :, None, None] + shift[None, :, None, None])
+    ref = ref.permute(0, 2, 3, 1).contiguous()
+    lib = L.load()
+    KY = ((3, 1), (2, 0))
+    xd = encode_h2(x.permute(0, 2, 3, 1).contiguous()).to(dev)
+    H2 = 2 * H
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    P.buf_floats += [cin * H * H, cout * H2 * H2]
+    for a in range(2):
+        for b in range(2):
+            w2 = torch.stack([torch.stack([w[:, :, KY[a][dy], KY[b][dx]] for dx in range(2)], -1) for dy in range(2)], -2).permute(1, 0, 2, 3).contiguous()
+            P.conv(f'p{a}{b}', Act(0, cin, H, H, cin), [w2], [scale], [shift], 2, 1, True, out_buf_special=1, out_cstride=2 * cout,
+                   out_coff=a * H2 * cout + b * cout, pad=(1 - a, 1 - b), out_rstride=2 * H2 * cout, out_bstride=H2 * H2 * cout)
+    for op in P.ops:
+        assert op.weight_h2
+        op.act_shift, op.in_fmt, op.out_fmt = ACT_SHIFT, L.FMT_H2, L.FMT_H2
+    buf = C.create_string_buffer(128)
+    names = {}
+    for mode, variant in [(0, -1)] + _variants(lib, P.ops[0], B):
+        out = torch.full((B, H2, H2, cout), float('nan'), device=dev)
+        for op in P.ops:
+            L.check(lib.romp_conv_forward(C.byref(op), L.ptr(xd), None, L.ptr(out), B, mode, variant, L.stream_ptr(dev)))
+        torch.cuda.synchronize()
+        L.check(lib.romp_conv_describe(C.byref(P.ops[0]), B, variant, buf, 128))
+        err = (decode_h2(out.cpu()) - ref).abs().max().item()
+        names[buf.value.decode()] = err
+        assert err < 5e-5, (buf.value, variant, err)
+    assert any(n.startswith('conv_h2g_k2s1') for n in names), names
+    print('deconv (H2) %d->%d @%d: %s' % (cin, cout, H, ', '.join('%s %.1e' % kv for kv in sorted(names.items()))))
+
+
 @pytest.mark.parametrize('cin,cout,H', [(256, 512, 128), (1024, 2048, 32)])
 def test_conv1x1_stride2(dev, cin, cout, H):
     from romp_amd import lib as L
