@@ -449,8 +449,8 @@ __device__ __forceinline__ void conv_epilogue_h2direct(const ConvParams& p, cons
 typedef void (*conv_fn)(ConvParams);
 // math: 0 f32 MFMA, 1 bf16x3 (register-staged weights), 2 bf16x3 (LDS-DMA weight rows), 3 / 4 the same two for f16x2,
 // 8 f16x2 with register-resident weights (conv_h2r.hip), 9 its stride-2 form on parity planes (conv_h2s.hip),
-// 10 the input channels split across the workgroup's waves (conv_h2k.hip: single-image plans), 11 the 1x1 streamed-K GEMM form (conv_h2g.hip).  (5 / 6 / 7 were round 2's LDS-DMA pipeline kernels, now
-// scripts/attic/conv_h2p.hip: never faster than 3 / 4 / 8 inside the network.)  threads: workgroup size (0 = 256, or 512 for the ping-pong kernels).
+// 10 the input channels split across the workgroup's waves (conv_h2k.hip: single-image plans), 11 the 1x1 streamed-K GEMM form (conv_h2g.hip).  (5 / 6 / 7 were round 2's LDS-DMA pipeline kernels: never
+// faster than 3 / 4 / 8 inside the network, deleted in round 6; their measurements are in profiles/r02_*.)  threads: workgroup size (0 = 256, or 512 for the ping-pong kernels).
 // o4: the same kernel compiled for four workgroups per CU (128 VGPRs; named conv_h2o).
 struct ConvVariant { int ks, s, mt, nt, tw, ck; conv_fn fn; int lds; int th; int occ; int pp; int math; int threads; int o4; };
 

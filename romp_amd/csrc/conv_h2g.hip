@@ -47,7 +47,7 @@ struct GCfg {
     static constexpr int PFU = 2;                              // fragment reads run PFU units ahead of their MFMAs
     static constexpr int PPE = KSUB * NI / NCH;                // DMA pieces issued per chunk end (= NI / 2)
     static_assert(NS == 1 || NS == 2 || NS == 4, "channel slices per workgroup");
-    static_assert(KS == 1 || (KS == 2 && S == 1), "1x1 (stride 1 / 2) or the 2x2 parity conv");
+    static_assert(KS == 1 || (KS == 2 && S == 1) || KS == 3, "1x1, the 2x2 parity conv, or 3x3 with one (tap, channel run) per stage");
     static_assert(NPIX % 32 == 0 && NI >= 2 && NI % 2 == 0, "the same number of whole pieces at every chunk end");
     static_assert((KSUB - 1) * SUB_BYTES + (P - 1) * 4096 < 65536, "fragment read offsets are ds_read immediates");
 };
@@ -237,12 +237,11 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
         ROMP_TRACE(11);
         if (last) {
             if (have_next) issue_ss(nxt, slot ^ 1);
-#ifndef ROMP_H2G_DRAIN_LATE
             // The next stage's DMA pieces and weights (issued inside the stage body above) are waited for HERE, in front of the epilogue:
-            // the item then ends on a barrier alone and its output stores stay in flight into the next item (the HBM-bound layers
-            // are 2-8 stages per item: a full drain behind the epilogue exposed one store round trip per item)
+            // the item then ends on a barrier alone and its output stores stay in flight into the next item.  (Measured against the
+            // full drain behind the epilogue, same box, all ten ResNet-50 shapes: equal to +-1 %, profiles/r06_h2g_drain_ab.txt --
+            // with two workgroups per CU the other one covers the store round trip either way.  Kept: it never waits for a store.)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             if (!(p.dbg & 4)) {
                 Item ce = cur;
                 ce.n0 += sl * 32;
@@ -283,12 +282,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
         buf ^= 1;
         // this wave's DMA pieces of the next stage have landed (and its weight registers); every wave is done reading the buffer
         // the stage after next will overwrite
-#ifndef ROMP_H2G_DRAIN_LATE
         if (ch == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (an item's last stage: drained in front of its epilogue)
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_s_barrier();
         ROMP_TRACE(12);
     }
@@ -308,6 +303,12 @@ static ConvVariant kVariantsH2g[] = {
     ROMP_CONV_VARIANT_H2G(1, 4, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(1, 2, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(1, 2, 2, 16, 2, 2),
     // the 2x2 parity convs of the three ConvTranspose2d(k4, s2, p1) layers (resnet_50.py:80-120): K = 4 taps x Cin, matrix-bound
     ROMP_CONV_VARIANT_H2G(2, 4, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 2, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 2, 2, 16, 1, 2), ROMP_CONV_VARIANT_H2G(2, 4, 2, 16, 1, 1),
+    // 3x3 in the same form -- no haloed tile: stage = (tap, 32 * KSUB channels), every tap's pixels fetched on their own as full 128-byte
+    // lines (9 instead of ~4.6 / ~1.7 fetched pixels per output pixel, out of L2, against half the weight bytes per MFMA of
+    // conv_h2s / conv_h2r at P = 4).  VERDICT r5 #4's experiment: the stride-2 class on full lines; stride 1 rides along for the tuner
+    ROMP_CONV_VARIANT_H2G(3, 4, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(3, 2, 4, 16, 2, 2), ROMP_CONV_VARIANT_H2G(3, 2, 4, 16, 2, 1), ROMP_CONV_VARIANT_H2G(3, 2, 2, 16, 2, 2),
+    ROMP_CONV_VARIANT_H2G(3, 2, 2, 16, 2, 1), ROMP_CONV_VARIANT_H2G(3, 2, 1, 16, 2, 1),
+    ROMP_CONV_VARIANT_H2G(3, 2, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(3, 4, 4, 16, 1, 2), ROMP_CONV_VARIANT_H2G(3, 2, 4, 16, 1, 4), ROMP_CONV_VARIANT_H2G(3, 2, 2, 16, 1, 2),
 };
 ConvVariant* conv_variants_h2g(int* n) { *n = (int)(sizeof(kVariantsH2g) / sizeof(kVariantsH2g[0])); return kVariantsH2g; }
 
