@@ -38,7 +38,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_{bf
 BX3_PRODUCTS = 6                  # bf16 piece products issued per f32 product by the bf16x3 kernels
 H2_PRODUCTS = 3                   # fp16 piece products issued per f32 product by the f16x2 kernels
 PEAK_HBM_GBS = 8000.0
-PROFILE_TAG = 'r05'               # profiles/<tag>_pmc_traffic_by_op.json: the committed rocprofv3 PMC passes of this build
+PROFILE_TAG = 'r06'               # profiles/<tag>_pmc_traffic_by_op.json: the committed rocprofv3 PMC passes of this build
 
 
 def parse_args():

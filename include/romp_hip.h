@@ -220,9 +220,9 @@ int  romp_net_range_scan(romp_net* net, const float* image_nhwc, int B, float* c
                          void* stream, float* maxabs_out_host, int32_t* nonfinite_out_host, int32_t* saturated_out_host);
 /* Saturation is observable: every kernel that splits values into the fp16 pieces of ROMP_FMT_H2 clamps at +-65504 / 2^act_shift
  * and reports a clamp into the net's device counter (one increment per wave and work item).  *count_host = events since
- * romp_net_create or the last call with reset != 0; 0 for a net inside its calibrated range.  The two register-resident
- * fused BasicBlock kernels count only in their checked builds: romp_net_set_sat_check(net, 1) (default: env ROMP_CHECK_FINITE=1)
- * and every romp_net_range_scan.  romp_net_saturated synchronises `stream`. */
+ * romp_net_create or the last call with reset != 0; 0 for a net inside its calibrated range.  Every kernel counts in every build
+ * (ABI 6: the two register-resident fused BasicBlock kernels too; romp_net_set_sat_check, which switched their counting builds on
+ * in ABI 5, is kept and changes nothing).  romp_net_saturated synchronises `stream`. */
 int  romp_net_saturated(romp_net* net, int64_t* count_host, int reset, void* stream);
 int  romp_net_set_sat_check(romp_net* net, int enable);
 /* Device address of that counter (an int32, cumulative like romp_net_saturated without reset): what romp_parse_watch's `watch`

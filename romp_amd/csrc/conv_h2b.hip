@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
     // a VALU instruction 4) and one step follows each MFMA, pinned there with a scheduling barrier.
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
     f32x16 acc2[2];                                            // (block 1's outlives its tile: finished under the next tile's conv1)
-    unsigned sat_pk = 0u;                                      // (DBG & 16, the checked build) per-half maximum of the high pieces formed: 0x7BFF iff clamped (sat_track_pk)
+    unsigned sat_pk = 0u;                                      // per-half maximum of the high pieces formed: 0x7BFF iff clamped (sat_track_pk)
     Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             case 5: split_b(ev[0], ev[1], eh[0], el[0]); break;
             case 10:
                 split_a(ev[2], ev[3], eh[1]);
-                if ((DBG & 16) && live) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);      // (not live: the first tile's pass over a block that does not exist)
+                if (live) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);      // (not live: the first tile's pass over a block that does not exist)
                 break;
             case 11: split_b(ev[2], ev[3], eh[1], el[1]); break;
             case 12: {
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             case 3: split_b(hv[0], hv[1], hh[0], ll[0]); break;
             case 6:
                 split_a(hv[2], hv[3], hh[1]);
-                if (DBG & 16) sat_pk = sat_track_pk(sat_pk, hh[0], hh[1]);       // (pixels outside the image are zeros)
+                sat_pk = sat_track_pk(sat_pk, hh[0], hh[1]);       // (pixels outside the image are zeros)
                 break;
             case 7: split_b(hv[2], hv[3], hh[1], ll[1]); break;
             case 8: if (act) *reinterpret_cast<uint2*>(m + unit_of(mx, (g4 & 1) * 2 + 0) * 16) = make_uint2(hh[0], hh[1]); break;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             unsigned eh[2], el[2];
             split2(ev[0], ev[1], eh[0], el[0]);
             split2(ev[2], ev[3], eh[1], el[1]);
-            if (DBG & 16) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);
+            sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);
             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
             const u32x2_t s0 = __builtin_amdgcn_permlane32_swap(eh[0], el[0], false, false);
             const u32x2_t s1 = __builtin_amdgcn_permlane32_swap(eh[1], el[1], false, false);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void bblock32_kernel(ConvParams p) {
             *reinterpret_cast<uint4*>(o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
     }
-    if (DBG & 16) sat_report_pk(p.sat, sat_pk);
+    sat_report_pk(p.sat, sat_pk);
 #undef SIDE_PIN
 }
 
@@ -504,11 +504,11 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     static float* zero = nullptr;                              // 256 bytes of zeros: what out-of-image lanes of the halo DMA fetch
     static int num_cu = 256;
     using KernelFn = void (*)(ConvParams);
-    static KernelFn fn = bblock32_kernel<0>;
-    const KernelFn fn_checked = bblock32_kernel<16>;            // the build that counts clamped values (conv_common.h sat_report)
+    static KernelFn fn = bblock32_kernel<0>;                    // (always counts the values it clamps: conv_common.h sat_track_pk)
     if (!attr) {                                               // (romp_net_create calls this path's setup outside any stream capture: bblock_init)
+#ifdef ROMP_BBLOCK_KNOCKOUTS                                   // the timing knock-outs: developer builds only (see conv_h2c.h)
         const char* e = getenv("ROMP_CONV_DEBUG");
-        switch (e ? atoi(e) : 0) {
+        switch ((e ? atoi(e) : 0) & 127) {
             case 0: break;
             case 1: fn = bblock32_kernel<1>; break;
             case 2: fn = bblock32_kernel<2>; break;
@@ -517,10 +517,10 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
             case 8: fn = bblock32_kernel<8>; break;
             case 15: fn = bblock32_kernel<15>; break;
             case 71: fn = bblock32_kernel<71>; break;
-            default: ROMP_REQUIRE(false, "bblock32: ROMP_CONV_DEBUG is one of 0 1 2 4 7 8 15 71 here");
+            default: ROMP_REQUIRE(false, "bblock32: ROMP_CONV_DEBUG & 127 is one of 0 1 2 4 7 8 15 71 here");
         }
+#endif
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
-        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_checked), hipFuncAttributeMaxDynamicSharedMemorySize, BCfg::LDS_BYTES));
         ROMP_HIP_CHECK(hipMalloc((void**)&zero, 256));
         ROMP_HIP_CHECK(hipMemset(zero, 0, 256));
         int dev = 0;
@@ -545,7 +545,6 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     p.queue = queue;
     p.trace = conv_trace_arm(st);
     p.sat = conv_sat_counter();
-    const bool checked = conv_sat_checked() && p.sat && fn == static_cast<KernelFn>(bblock32_kernel<0>);
     {
         const unsigned long long bytes = ((unsigned long long)B * op.H * op.W * op1.in_cstride - op1.in_coff) * 4ull;
         ROMP_REQUIRE(bytes < 0x80000000ull, "bblock32: input tensor of %llu bytes: beyond the 31-bit offsets of the halo fetch", bytes);
@@ -568,7 +567,7 @@ int launch_bblock32(const romp_op& op1, const romp_op& op, const float* x, float
     long grid = num_cu;                                        // one workgroup per CU
     if (grid > p.tiles_total) grid = p.tiles_total;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(checked ? fn_checked : fn, dim3((unsigned)grid), dim3(256), BCfg::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), BCfg::LDS_BYTES, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

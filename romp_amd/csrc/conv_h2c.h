@@ -63,9 +63,11 @@ struct RCfg {
 
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 
-// DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / parking, 4 no finish, 8 no MFMA;
-// 16: the CHECKED build (correct outputs): also counts values clamped at +-65504 on their way into fp16 pieces (conv_common.h
-// sat_report; romp_net_range_scan and ROMP_CHECK_FINITE=1 run it -- two more VALU per four values of side work)
+// DBG: timing knock-outs (env ROMP_CONV_DEBUG, wrong outputs): 1 no halo DMA, 2 no hand-over / parking, 4 no finish, 8 no MFMA --
+// instantiated only in a developer build (-DROMP_BBLOCK_KNOCKOUTS: python -m romp_amd.build with extra_flags; scripts/bblock_bench.py),
+// five more copies of a fully unrolled kernel are most of this file's compile time.  The product kernel (DBG = 0) ALWAYS counts the
+// values it clamps at +-65504 on their way into fp16 pieces (round 6: conv_common.h sat_track_pk, one v_pk_maximum3_f16 per four
+// values; rounds 4-5 had a separate "checked" instantiation that cost 1.7-2 % of the job, profiles/r06_guard_cost*.txt)
 template <int C, int DBG>
 __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvParams p) {
     using X = RCfg<C>;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #define SIDE_PIN() __builtin_amdgcn_sched_barrier(0)
 
     f32x4c acc2[X::THW];                                        // (the last row's outlives its tile: finished under the next tile's first MFMAs)
-    unsigned sat_pk = 0u;                                       // (DBG & 16) per-half maximum of the high pieces formed: a half == 0x7BFF iff a value was clamped (conv_common.h sat_track_pk)
+    unsigned sat_pk = 0u;                                       // per-half maximum of the high pieces formed: a half == 0x7BFF iff a value was clamped (conv_common.h sat_track_pk)
     Item itp = it;
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
                 break; }
             case 5:
                 eh[0] = pack_hi(ev[0], ev[1]); eh[1] = pack_hi(ev[2], ev[3]);
-                if ((DBG & 16) && live) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);      // (not live: the first tile's pass over a row that does not exist)
+                if (live) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);      // (not live: the first tile's pass over a row that does not exist)
                 break;
             case 6: el[0] = h2_low_pair(eh[0], ev[0], ev[1]); el[1] = h2_low_pair(eh[1], ev[2], ev[3]); break;
             case 7: {
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
                 break; }
             case 2:
                 hh[0] = pack_hi(hv[0], hv[1]); hh[1] = pack_hi(hv[2], hv[3]);
-                if (DBG & 16) sat_pk = sat_track_pk(sat_pk, hh[0], hh[1]);       // (pixels outside the image are zeros)
+                sat_pk = sat_track_pk(sat_pk, hh[0], hh[1]);       // (pixels outside the image are zeros)
                 break;
             case 3: hl[0] = h2_low_pair(hh[0], hv[0], hv[1]); hl[1] = h2_low_pair(hh[1], hv[2], hv[3]); break;
             case 4: if (act) *reinterpret_cast<uint2*>(sBuf + addr) = make_uint2(hh[0], hh[1]); break;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
             ev[e] = (e & 1) ? add_pieces_relu<1>(v, wh, wl, H2_MAX) : add_pieces_relu<0>(v, wh, wl, H2_MAX);
         }
         unsigned eh[2] = {pack_hi(ev[0], ev[1]), pack_hi(ev[2], ev[3])};
-        if (DBG & 16) sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);
+        sat_pk = sat_track_pk(sat_pk, eh[0], eh[1]);
         unsigned el[2] = {h2_low_pair(eh[0], ev[0], ev[1]), h2_low_pair(eh[1], ev[2], ev[3])};
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t a = __builtin_amdgcn_permlane16_swap(eh[0], el[0], false, false);
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
         float* o = p.out + (size_t)itp.b * p.out_bs + p.out_co + (unsigned)((oy * p.out_rs + ox * p.out_cs) + (16 * cg + 4 * q));
         *reinterpret_cast<uint4*>(o) = make_uint4(a[0], b[0], a[1], b[1]);
     }
-    if (DBG & 16) sat_report_pk(p.sat, sat_pk);
+    sat_report_pk(p.sat, sat_pk);
 #undef SIDE_PIN
 }
 
@@ -511,20 +513,20 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     static int num_cu = 256;
     using KernelFn = void (*)(ConvParams);
     static KernelFn fn = bblockr_kernel<C, 0>;
-    const KernelFn fn_checked = bblockr_kernel<C, 16>;
     if (!attr) {                                               // (romp_net_create calls this path's set-up outside any stream capture)
+#ifdef ROMP_BBLOCK_KNOCKOUTS
         const char* e = getenv("ROMP_CONV_DEBUG");
-        switch (e ? atoi(e) : 0) {
+        switch ((e ? atoi(e) : 0) & 15) {                      // (the other bits belong to other kernels)
             case 0: break;
             case 1: fn = bblockr_kernel<C, 1>; break;
             case 2: fn = bblockr_kernel<C, 2>; break;
             case 4: fn = bblockr_kernel<C, 4>; break;
             case 7: fn = bblockr_kernel<C, 7>; break;
             case 8: fn = bblockr_kernel<C, 8>; break;
-            default: ROMP_REQUIRE(false, "bblock%d: ROMP_CONV_DEBUG is one of 0 1 2 4 7 8 here", C);
+            default: ROMP_REQUIRE(false, "bblock%d: ROMP_CONV_DEBUG & 15 is one of 0 1 2 4 7 8 here", C);
         }
+#endif
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
-        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_checked), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
         int dev = 0;
         hipDeviceProp_t prop;
         ROMP_HIP_CHECK(hipGetDevice(&dev));
@@ -546,7 +548,6 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     p.queue = queue;
     p.trace = conv_trace_arm(st);
     p.sat = conv_sat_counter();
-    const bool checked = conv_sat_checked() && p.sat && fn == static_cast<KernelFn>(bblockr_kernel<C, 0>);
     {
         const unsigned long long bytes = ((unsigned long long)B * op.H * op.W * op1.in_cstride - op1.in_coff) * 4ull;
         ROMP_REQUIRE(bytes < 0x80000000ull, "bblock%d: input tensor of %llu bytes: beyond the 31-bit offsets of the halo fetch", C, bytes);
@@ -570,7 +571,7 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     long grid = (long)num_cu * ((cap > 0 && cap < X::WG_PER_CU) ? cap : X::WG_PER_CU);
     if (grid > p.tiles_total) grid = p.tiles_total;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(checked ? fn_checked : fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

@@ -15,9 +15,10 @@ from .plan import Program, build_romp_hrnet32, coord_channels, decode_h2, encode
 
 
 _CHECK_FINITE = os.environ.get('ROMP_CHECK_FINITE', '0') not in ('', '0')
-# The range guard (RangeGuard below) is ON by default.  ROMP_RANGE_GUARD exists for measuring what it costs, not as a product option:
-# '0' = no guard (the round-5 behaviour: clamped maps pass silently), 'nofused' = guard without the counting builds of the two
-# register-resident fused BasicBlock kernels (their clamps then go unseen).
+# The range guard (RangeGuard below) is ON by default.  ROMP_RANGE_GUARD=0 exists for measuring what it costs, not as a product
+# option: no guard (the round-5 behaviour: clamped maps pass silently).  Every kernel that forms fp16 pieces counts its clamps in
+# every build (the two fused BasicBlock kernels since round 6: one v_pk_maximum3_f16 per four values), so there is nothing else to
+# switch: the guard's own cost is the read-back, measured inside the run-to-run spread (profiles/r06_guard_cost_packed.txt).
 _RANGE_GUARD = os.environ.get('ROMP_RANGE_GUARD', '1')
 
 
@@ -25,8 +26,7 @@ class RangeGuard:
     """Default-on range safety of the f16x2 arithmetic.  The reference's network is float32 and has no range to leave
     (simple_romp/romp/main.py:106-115); the f16x2 kernels clamp a value beyond 65504 / 2^act_shift while splitting it into fp16
     pieces -- finite, wrong -- and calibration (RompNet._measure_ranges) can only vouch for the frames it saw.  Every clamp bumps
-    the net's device counter (conv_common.h sat_report; the fused BasicBlock kernels in their counting builds, which the guard
-    switches on).  The API reads that counter back WITH the detection count of every call (romp_parse_watch: the same D2H, the
+    the net's device counter (conv_common.h sat_report / sat_report_pk: every kernel, every build).  The API reads that counter back WITH the detection count of every call (romp_parse_watch: the same D2H, the
     same synchronisation -- no extra round trip) and hands it to `check`; a change means this call clamped somewhere, and the
     caller re-runs it on the exact-f32 program of the same weights (`RompNet.f32_twin`, built on first need) -- so no call of the
     API returns clamped maps.  Pipelined callers (ROMP.forward_chunks) have the NEXT network already in flight when they read the
@@ -37,8 +37,6 @@ class RangeGuard:
         self.enabled = bool(net.bf16x3) and _RANGE_GUARD != '0'
         self.seen, self.carry, self.reruns, self.warned = 0, False, 0, False
         if self.enabled:
-            if _RANGE_GUARD != 'nofused':
-                net.set_sat_check(True)
             self.seen = net.saturated & 0xffffffff
 
     @property
@@ -355,8 +353,7 @@ class RompNet:
     def saturated(self):
         """Saturation events since the net was built (or `reset_saturated()`): how many (wave, work item) times a kernel clamped a
         value at +-65504 while splitting it into the fp16 pieces of the H2 format -- 0 for a net inside its calibrated range.
-        Synchronises the current stream.  The two register-resident fused BasicBlock kernels count only under
-        ROMP_CHECK_FINITE=1 / `set_sat_check(True)` and in `range_scan`."""
+        Synchronises the current stream."""
         v = C.c_int64(0)
         L.check(self.lib.romp_net_saturated(self._h, C.byref(v), 0, L.stream_ptr(self.device)))
         return int(v.value)
@@ -367,7 +364,8 @@ class RompNet:
         return int(v.value)
 
     def set_sat_check(self, enable):
-        """Run the counting builds of the fused BasicBlock kernels too (a little slower; the default follows ROMP_CHECK_FINITE)."""
+        """(Rounds 4-5: run the counting builds of the fused BasicBlock kernels.  Since round 6 those kernels always count; the call is
+        kept for hosts written against ABI 5 and changes nothing.)"""
         L.check(self.lib.romp_net_set_sat_check(self._h, int(bool(enable))))
 
     def range_scan(self, image):

@@ -1,5 +1,8 @@
 """Time the fused 32-channel BasicBlock kernel (csrc/conv_h2b.hip) against the same block as two conv launches.
-usage: [BB_C=32|64] [BB_B=32] [BB_H=128|64] python scripts/bblock_bench.py      (GPU; ROMP_FUSE_BLOCKS=0 gives the unfused lowering)"""
+usage: [BB_C=32|64] [BB_B=32] [BB_H=128|64] python scripts/bblock_bench.py      (GPU; ROMP_FUSE_BLOCKS=0 gives the unfused lowering)
+The phase knock-outs (ROMP_CONV_DEBUG = 1 2 4 7 8 for the fused kernels) exist in a developer build only since round 6:
+    python -c "from romp_amd import build as b; b.build(extra_flags=['-DROMP_BBLOCK_KNOCKOUTS'], lib='romp_amd/libromp_hip_ko.so', objdir='romp_amd/build_ko')"
+    ROMP_HIP_LIB=romp_amd/libromp_hip_ko.so ROMP_CONV_DEBUG=8 python scripts/bblock_bench.py"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -21,7 +21,7 @@ FILES = {'h2x': ('conv_h2x.hip', []), 'h2c': ('conv_h2c.hip', ['-mllvm', '-pragm
          'h2c32': ('conv_h2c32.hip', ['-mllvm', '-pragma-unroll-threshold=1000000'])}
 EXPECT = {'seam1x1_kernelILi0ELi0E': (52, 'loop'), 'seam1x1_kernelILi1ELi0E': (20, 'loop'),
           'bblockr_kernelILi64ELi0E': (6, 'layout'), 'bblockr_kernelILi32ELi0E': (3, 'layout'),
-          'bblockr_kernelILi64ELi16E': (6, 'layout'), 'bblockr_kernelILi32ELi16E': (3, 'layout')}
+          }
 VMEM = re.compile(r'^\s*(global_load|global_store|buffer_load|buffer_store|global_atomic|buffer_atomic|flat_load|flat_store|scratch_)')
 
 
