@@ -234,6 +234,10 @@ void romp_net_destroy(romp_net* net);
 int  romp_conv_forward(const romp_op* op_host, const float* in, const float* res, float* out,
                        int B, int mode, int variant, void* stream);
 int  romp_conv_num_variants(void);
+/* Kernel variants of one family in THIS build (ConvVariant.math: 0 f32 MFMA, 1 / 2 bf16x3, 3 / 4 f16x2 generic, 8 conv_h2r, 9 conv_h2s,
+ * 10 conv_h2k, 11 conv_h2g).  The bf16x3 family is optional (ROMP_WITH_BX3=1 python -m romp_amd.build): 0 means `--conv_math bf16x3`
+ * cannot be served by this library. */
+int  romp_conv_family_variants(int math);
 /* Developer aid: with env ROMP_CONV_TRACE=1 the split-precision conv kernels stamp their phases (s_memtime) per wave;
  * copies the stamps of the most recent launch (64 words per wave: count, then (time << 8 | event)) to the host and
  * returns the number of words, or < 0.  Synchronises the device. */

@@ -38,6 +38,7 @@ int launch_conv(const romp_op& op, const float* in, const float* res, float* out
                 int mode, int variant, int* queue, hipStream_t st, int wg_cap = 0);
 int describe_conv(const romp_op& op, int B, int variant, char* out, int n);
 int conv_num_variants();
+int conv_family_variants(int math);                              // variants of one kernel family (ConvVariant.math) in this build
 int conv_trace_read(unsigned long long* dst_host, int max_words);
 int conv_init();
 bool conv_variant_valid(const romp_op& op, int variant);

@@ -37,13 +37,18 @@ __global__ void conv_naive_kernel(ConvParams p, int KS, int S, int B, int groups
 // ------------------------------------------------------------------------------------------------
 // dispatch
 // ------------------------------------------------------------------------------------------------
+// The bf16x3 family (conv_bx3.hip: 26 instantiations, a minute of compile time) is an OPTIONAL part of the library since round 6: no
+// committed variant table selects it (f16x2 is faster and as accurate), `--conv_math bf16x3` remains a tested arithmetic mode of a
+// build made with ROMP_WITH_BX3=1 (romp_amd/build.py).  Without conv_bx3.o this weak definition answers: no variants.
+__attribute__((weak)) ConvVariant* conv_variants_bx3(int* n) { *n = 0; return nullptr; }
+
 static std::vector<ConvVariant> kVariants;
 static int kNumVariants = 0;
 static void collect_variants() {
     if (kNumVariants) return;
     int n = 0;
     ConvVariant* t = conv_variants_f32(&n); kVariants.insert(kVariants.end(), t, t + n);
-    t = conv_variants_bx3(&n); kVariants.insert(kVariants.end(), t, t + n);
+    t = conv_variants_bx3(&n); if (n) kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2d(&n); kVariants.insert(kVariants.end(), t, t + n);
     t = conv_variants_h2r(&n); kVariants.insert(kVariants.end(), t, t + n);
@@ -144,6 +149,12 @@ static void out_dims(const romp_op& op, int* Ho, int* Wo) {
 }
 
 int conv_num_variants() { collect_variants(); return kNumVariants; }
+int conv_family_variants(int math) {
+    collect_variants();
+    int c = 0;
+    for (const ConvVariant& v : kVariants) c += v.math == math;
+    return c;
+}
 
 bool conv_variant_valid(const romp_op& op, int variant);
 bool conv_variant_tunable(const romp_op& op, int variant) { return conv_variant_valid(op, variant); }

@@ -939,6 +939,7 @@ int romp_conv_forward(const romp_op* op, const float* in, const float* res, floa
 }
 
 int romp_conv_num_variants(void) { return conv_num_variants(); }
+int romp_conv_family_variants(int math) { return conv_family_variants(math); }
 
 int romp_conv_trace_read(unsigned long long* dst_host, int max_words) { return conv_trace_read(dst_host, max_words); }
 

@@ -79,6 +79,7 @@ def load():
         'romp_net_destroy': (None, [vp]),
         'romp_conv_forward': (C.c_int, [C.POINTER(RompOp), vp, vp, vp, i32, i32, i32, vp]),
         'romp_conv_num_variants': (C.c_int, []),
+        'romp_conv_family_variants': (C.c_int, [i32]),
         'romp_conv_trace_read': (C.c_int, [C.POINTER(C.c_uint64), i32]),
         'romp_conv_describe': (C.c_int, [C.POINTER(RompOp), i32, i32, C.c_char_p, i32]),
         'romp_net_autotune': (C.c_int, [vp, i32, i32, vp]),
@@ -129,10 +130,16 @@ def load():
 
 EXPORTS = ['romp_abi_version', 'romp_last_error', 'romp_net_create', 'romp_net_forward', 'romp_net_read_buffer',
            'romp_net_write_buffer', 'romp_net_set_mode', 'romp_net_set_graph', 'romp_net_set_streams', 'romp_net_profile', 'romp_net_range_scan', 'romp_net_saturated', 'romp_net_set_sat_check', 'romp_net_destroy',
-           'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_trace_read', 'romp_conv_describe',
+           'romp_conv_forward', 'romp_conv_num_variants', 'romp_conv_family_variants', 'romp_conv_trace_read', 'romp_conv_describe',
            'romp_net_load', 'romp_net_plan_info', 'romp_net_plan_kind', 'romp_net_autotune', 'romp_net_tuned_variant', 'romp_net_set_tuned', 'romp_net_set_split', 'romp_project_verts', 'romp_estimate_translation', 'romp_cam_to_trans', 'romp_bev_project_verts', 'romp_oneeuro_state_floats', 'romp_oneeuro_smooth', 'romp_sim3dr_normals', 'romp_sim3dr_light', 'romp_sim3dr_rasterize', 'romp_bev_workspace_ints', 'romp_bev_parse', 'romp_bev_regress',
            'romp_net_buffer_ptr', 'romp_parse', 'romp_parse_watch', 'romp_net_sat_counter', 'romp_rot6d_to_aa', 'smpl_ctx_create', 'smpl_forward', 'smpl_ctx_destroy',
            'romp_project', 'romp_preprocess', 'romp_preprocess_batch', 'romp_bev_postprocess']
+
+
+def has_bf16x3():
+    """Does this build of the library carry the optional bf16x3 kernel family (ROMP_WITH_BX3=1 python -m romp_amd.build)?"""
+    h = load()
+    return h.romp_conv_family_variants(1) + h.romp_conv_family_variants(2) > 0
 
 
 def check(rc):

@@ -52,7 +52,7 @@ def romp_settings(input_args=sys.argv[1:]):
     parser.add_argument('--webcam_id', type=int, default=0, help='The Webcam ID.')
     parser.add_argument('--max_batch', type=int, default=32, help='[romp_amd] largest batch forward_batch will be called with')
     parser.add_argument('--conv_math', type=str, default='f16x2', choices=['f32', 'bf16x3', 'f16x2', 'all'],
-                        help='[romp_amd] f32: exact-f32 MFMA kernels only; f16x2 (default) / bf16x3: also offer the f32-accurate split-precision kernels '
+                        help='[romp_amd] f32: exact-f32 MFMA kernels only; f16x2 (default) / bf16x3 (needs a library built with ROMP_WITH_BX3=1): also offer the f32-accurate split-precision kernels '
                              '(2 fp16 pieces, 3 products / 3 bf16 pieces, 6 products) on the 16-bit matrix pipe, chosen per layer by measurement the first '
                              'time a batch size is seen; all: both families')
     parser.add_argument('--backbone', type=str, default='hrnet32', choices=['hrnet32', 'resnet50'],

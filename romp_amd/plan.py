@@ -145,7 +145,13 @@ def set_conv_math(P, conv_math):
         conv_math = 'f32'
     assert conv_math in ('f32', 'bf16x3', 'f16x2', 'all'), conv_math
     P.conv_math = conv_math
-    P.bf16x3 = conv_math in ('bf16x3', 'all')
+    # the bf16x3 family is an optional part of the library (round 6: no committed table selects it): 'bf16x3' needs a build that has it,
+    # 'all' means "every split family this build offers"
+    from . import lib as _L
+    if conv_math == 'bf16x3' and not _L.has_bf16x3():
+        raise _L.RompHipError("conv_math='bf16x3': this libromp_hip.so was built without the bf16x3 kernel family "
+                              "(ROMP_WITH_BX3=1 python -m romp_amd.build --force); the default split arithmetic is 'f16x2'")
+    P.bf16x3 = conv_math == 'bf16x3' or (conv_math == 'all' and _L.has_bf16x3())
     P.f16x2 = conv_math in ('f16x2', 'all')
 
 

@@ -53,12 +53,14 @@ def test_romp_op_struct_layout_matches_header():
                     RompOp.relu_from.offset, RompOp.term_coff.offset]
 
 
-def test_fused_block_dispatch_flag_follows_the_weight_pack():
+def test_fused_block_dispatch_flag_follows_the_weight_pack(monkeypatch):
     """the fused-block launchers dispatch on ROMP_OPF_WAVE16, never on weight_aux != NULL.  conv_math='all'
     leaves the bf16x3 pack in every conv's weight_aux; a single-image plan fuses the 32-channel blocks WITHOUT the per-wave
-    repack, so its BBLOCK32 ops must carry weight_aux (stale bf16x3 bytes) but NOT the flag; the batch plan repacks and flags."""
+    repack, so its BBLOCK32 ops must carry weight_aux (stale bf16x3 bytes) but NOT the flag; the batch plan repacks and flags.
+    (The bf16x3 KERNELS are an optional part of the library since round 6; the pack is host code and is forced on here.)"""
     from romp_amd import lib as L, synthetic as S
     from romp_amd.plan import build_romp_hrnet32
+    monkeypatch.setattr(L, 'has_bf16x3', lambda: True)
     sd = S.make_romp_state_dict(0)
     for math in ('all', 'f16x2'):
         single = build_romp_hrnet32(sd, 'cpu', 512, bf16x3=math, split_k_items=128)
@@ -76,6 +78,25 @@ def test_fused_block_dispatch_flag_follows_the_weight_pack():
         for i in fused:
             for o in (batch.ops[i - 1], batch.ops[i]):
                 assert (o.flags & L.OPF_WAVE16) and o.weight_aux
+
+
+def test_bf16x3_family_is_an_optional_part_of_the_library():
+    """Round 6: no committed variant table selects a bf16x3 kernel, so conv_bx3.hip is compiled only on request
+    (ROMP_WITH_BX3=1 python -m romp_amd.build).  A library without it says so (romp_conv_family_variants), `conv_math='bf16x3'`
+    fails loudly instead of silently running other kernels, 'all' means every split family the build offers."""
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, set_conv_math
+    h = L.load()
+    assert h.romp_conv_family_variants(0) > 0 and h.romp_conv_family_variants(11) > 0          # f32 MFMA, conv_h2g
+    P = Program('cpu')
+    if L.has_bf16x3():
+        set_conv_math(P, 'bf16x3')
+        assert P.bf16x3 and not P.f16x2
+    else:
+        with pytest.raises(L.RompHipError, match='ROMP_WITH_BX3'):
+            set_conv_math(P, 'bf16x3')
+        set_conv_math(P, 'all')
+        assert P.f16x2 and not P.bf16x3
 
 
 def test_no_cpu_fallback_in_product_path():

@@ -22,6 +22,16 @@ from oracle import romp_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _has_bx3():
+    from romp_amd import lib
+    return lib.has_bf16x3()
+
+
+# the bf16x3 kernel family is an optional part of the library since round 6 (ROMP_WITH_BX3=1 python -m romp_amd.build): its
+# parametrisations run in a build that has it
+BX3 = pytest.param('bf16x3', marks=pytest.mark.skipif(not _has_bx3(), reason='library built without the bf16x3 family (ROMP_WITH_BX3=1)'))
+
+
 @pytest.fixture(scope='module')
 def dev():
     assert torch.cuda.is_available(), 'GPU tests need the MI355X'
@@ -598,7 +608,7 @@ def test_net_vs_oracle_batch(dev, net0):
     assert torch.equal(c1.unsqueeze(1), cm) and torch.equal(c2, c1)
 
 
-@pytest.mark.parametrize('conv_math', ['bf16x3', 'f16x2'])
+@pytest.mark.parametrize('conv_math', [BX3, 'f16x2'])
 def test_net_bf16x3_parity(dev, golden_dir, conv_math):
     """conv_math='bf16x3' / 'f16x2': every conv the autotuner moves onto the 16-bit matrix pipe (3 bf16 pieces and six
     piece products, or 2 fp16 pieces and three, f32 accumulation) must pass the SAME gates as the f32-MFMA network:
@@ -846,7 +856,7 @@ def test_net_full_batch_properties(dev):
     assert torch.isfinite(pm).all()
 
 
-@pytest.mark.parametrize('B,conv_math', [(32, 'f16x2'), (32, 'bf16x3'), (128, 'f16x2')])
+@pytest.mark.parametrize('B,conv_math', [(32, 'f16x2'), pytest.param(32, 'bf16x3', marks=BX3.marks), (128, 'f16x2')])
 def test_net_benchmark_batch_vs_oracle(dev, B, conv_math):
     """The sizes bench.py times (BASELINE configs[1]: B=32; the per-GPU shard of configs[2]: B=128), with the kernel
     variants the autotuner picks AT THAT SIZE: images {0, 7, 19, B-1} of the batch against the oracle network (1e-4), and the
