@@ -935,12 +935,14 @@ def test_stem_mfma_vs_torch(dev, kernel, B, H, W):
 
 
 @pytest.mark.parametrize('max_batch', [1, 2])
-def test_net_conv_math_all_single_image(dev, max_batch):
+def test_net_conv_math_all_single_image(dev, max_batch, monkeypatch):
     """conv_math='all' in a single-image plan: every conv carries the bf16x3 pack in weight_aux, the
     32-channel blocks are fused WITHOUT the per-wave repack -- the fused launcher must dispatch on ROMP_OPF_WAVE16, not on
-    weight_aux != NULL (it used to run the row-pipelined kernel on bf16x3 bytes: silently wrong maps)."""
+    weight_aux != NULL (it used to run the row-pipelined kernel on bf16x3 bytes: silently wrong maps).  (The bf16x3 KERNELS are an
+    optional part of the library since round 6; the host-side pack is forced on here -- stale bytes in weight_aux are the point.)"""
     from romp_amd import lib as L
     from romp_amd.net import RompNet
+    monkeypatch.setattr(L, 'has_bf16x3', lambda: True)
     sd = O.make_romp_state_dict(0)
     net = RompNet(sd, dev, max_batch=max_batch, bf16x3='all')
     blocks = [o for o in net.program.ops if o.kind == L.OP_BBLOCK32]
