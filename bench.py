@@ -129,7 +129,7 @@ def roofline_report(net, images, pmc_workload=None):
     # 3 (f16x2) 16-bit MFMA products per algorithmic product, so its matrix roof is the 16-bit dense peak / products; the f32
     # kernels are priced against the f32 MFMA peak.  The HBM view of the same kernel is reported beside it (hbm_frac): with
     # three products the 3x3 layers sit near the ridge, and whichever fraction is larger is the binding roof.
-    bx3, h2 = 'conv_bx' in name, ('conv_h2' in name or name.startswith('bblock') or name in ('seam1x1', 'fuseup'))
+    bx3, h2 = 'conv_bx' in name, ('conv_h2' in name or name.startswith('bblock') or name in ('seam1x1', 'seam1x1_ds', 'fuseup', 'stem2'))
     products = BX3_PRODUCTS if bx3 else H2_PRODUCTS if h2 else 1
     peak = PEAK_BF16_MFMA_TFLOPS / products if (bx3 or h2) else PEAK_F32_MFMA_TFLOPS
     hbm_gbs = a['bytes'] / (a['ms'] * 1e-3) / 1e9

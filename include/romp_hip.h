@@ -100,6 +100,10 @@ const char* romp_last_error(void);
                                    an HRNet stage is one region; a fuse output waits for exactly the tensors it sums, the next
                                    module's branch follows its own fuse output in stream order).  Event numbers are unique per
                                    program; with streams off both kinds do nothing (op order is a valid serial order)           */
+#define ROMP_OP_STEM2     19    /* HRNet's whole stem as one kernel (csrc/stem2.hip, plan.fuse_stem2; model.py:384-390): the op before it
+                                   (NOP, fields intact, in_buf = ROMP_BUF_IMAGE) is the ROMP_OP_STEM 3 -> 64 conv, this op the 3x3 stride-2
+                                   64 -> 64 conv + BN + ReLU that read its output; the 64-channel half-resolution tensor between them
+                                   is never written.  weight_aux = this conv's per-wave f16x2 pack (ROMP_OPF_WAVE16), H2 output        */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 /* romp_op.flags */

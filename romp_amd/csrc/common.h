@@ -55,6 +55,7 @@ int launch_bblock64(const romp_op& op1, const romp_op& op2, const float* x, floa
 int launch_bblock32(const romp_op& op1, const romp_op& op2, const float* x, float* y, int B, int* queue, hipStream_t st);
 int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
 int launch_stem7(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
+int launch_stem2(const romp_op& stem, const romp_op& op, const float* image, float* out, int B, hipStream_t st);   // stem2.hip (image == out == nullptr: set-up only)
 int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStream_t st);
 struct FuseTerm { const float* ptr; int shift; int cstride; int fmt; };
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,

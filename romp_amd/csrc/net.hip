@@ -51,6 +51,7 @@ struct romp_net {
     int use_graph = 0;
     bool image_only_in_op0 = false;      // ops[0] is a stem and no later op reads ROMP_BUF_IMAGE (checked at create): graph replay may then
                                          // launch the stem eagerly and key the graph without the image pointer
+    int eager_ops = 1;                   // ops of that eager prefix: 1 (a stem), 2 (the NOP holding the stem + ROMP_OP_STEM2)
     int use_streams = 1;                 // run FORK/JOIN regions on side streams
     // Batch lanes: with split == 2 a forward of B images runs as two independent half-batch op sequences
     // on two streams (lane 0 on the caller's stream), each conv capped at one workgroup per CU, so the
@@ -204,6 +205,12 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             float* y = resolve_out(n, op.out_buf, center, params);
             ROMP_REQUIRE(x && y && n->ops[idx - 1].in_buf == op.res_buf, "bblock64: bad buffers %d -> %d", op.res_buf, op.out_buf);
             return launch_bblock64(n->ops[idx - 1], op, x, y, B, queue, st);
+        }
+        case ROMP_OP_STEM2: {
+            ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP && n->ops[idx - 1].in_buf == ROMP_BUF_IMAGE, "stem2: the op before it must be the NOP holding the stem");
+            float* y = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(image && y, "stem2: bad buffers");
+            return launch_stem2(n->ops[idx - 1], op, image, y, B, st);
         }
         case ROMP_OP_SEAM1X1: {
             ROMP_REQUIRE(idx > 0 && n->ops[idx - 1].kind == ROMP_OP_NOP, "seam1x1: the op before it must be the NOP holding the first conv");
@@ -446,6 +453,12 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
             if (rc) return rc;
             break;
         }
+    for (int i = 1; i < n_ops; ++i)
+        if (ops_host[i].kind == ROMP_OP_STEM2) {
+            const int rc = launch_stem2(ops_host[i - 1], ops_host[i], nullptr, nullptr, 0, nullptr);
+            if (rc) return rc;
+            break;
+        }
     for (int i = 0; i < n_ops; ++i)                            // (every instantiation in use: cheap, idempotent)
         if (ops_host[i].kind == ROMP_OP_FUSEUP) {
             const int rc = launch_fuseup(ops_host[i], nullptr, nullptr, 0, nullptr);
@@ -470,7 +483,11 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
     n->max_batch = max_batch;
     // graph replay launches op 0 eagerly and bakes no image pointer into the graph: only sound if nothing else reads the image
     n->image_only_in_op0 = n_ops > 0 && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
-    for (int i = 1; i < n_ops && n->image_only_in_op0; ++i) {
+    if (n_ops > 1 && n->ops[0].kind == ROMP_OP_NOP && n->ops[0].in_buf == ROMP_BUF_IMAGE && n->ops[1].kind == ROMP_OP_STEM2) {
+        n->image_only_in_op0 = true;                           // the fused stem: the NOP that holds the stem's fields + the kernel's op
+        n->eager_ops = 2;
+    }
+    for (int i = n->eager_ops; i < n_ops && n->image_only_in_op0; ++i) {
         const romp_op& o = n->ops[i];
         bool reads = o.in_buf == ROMP_BUF_IMAGE || o.res_buf == ROMP_BUF_IMAGE;
         for (int k = 0; k < 4; ++k) reads |= ((o.kind == ROMP_OP_FUSESUM || o.kind == ROMP_OP_FUSEUP) && k < o.n_terms && o.term_buf[k] == ROMP_BUF_IMAGE);
@@ -601,10 +618,10 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     if (!lanes_active(n, B)) {
         const GraphKey key{B, key_image, center, params, -1};
         if (stem_out) {
-            const int rc0 = run_op(n, 0, -1, image, B, center, params, st);
+            const int rc0 = run_op(n, n->eager_ops - 1, -1, image, B, center, params, st);     // (the ops in front of it in the prefix are NOPs)
             if (rc0) return rc0;
         }
-        const int rc = build(key, image, B, center, params, 0, 0, stem_out ? 1 : 0, true);
+        const int rc = build(key, image, B, center, params, 0, 0, stem_out ? n->eager_ops : 0, true);
         if (rc) return rc;
         ROMP_HIP_CHECK(hipGraphLaunch(n->graphs[key], st));
         return ROMP_OK;
@@ -798,6 +815,7 @@ static bool op_out_region(const romp_op& op, long long* npix, int* cs, int* coff
             break; }
         case ROMP_OP_STEM: case ROMP_OP_STEM7: Ho = op.H / 2; Wo = op.W / 2; *C = op.Cout; break;
         case ROMP_OP_FUSESUM: case ROMP_OP_FUSEUP: case ROMP_OP_KSUM: case ROMP_OP_BBLOCK32: case ROMP_OP_BBLOCK64: case ROMP_OP_SEAM1X1: *C = op.Cout; break;
+        case ROMP_OP_STEM2: Ho = op.H / 2; Wo = op.W / 2; *C = op.Cout; break;      // (H x W of the op: conv2's input size)
         default: return false;
     }
     *npix = (long long)Ho * Wo; *cs = op.out_cstride; *coff = op.out_coff;
@@ -954,6 +972,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_NOP) { snprintf(out, n, "nop"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK32) { snprintf(out, n, "bblock32"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK64) { snprintf(out, n, "bblock64"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_STEM2) { snprintf(out, n, "stem2"); return ROMP_OK; }
     if (op->kind == ROMP_OP_SEAM1X1) { snprintf(out, n, (op->flags & ROMP_OPF_SEAM_DS) ? "seam1x1_ds" : "seam1x1"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }

@@ -16,6 +16,7 @@ FMT_F32, FMT_H2 = 0, 1
 OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN, OP_BEV_PACK, OP_BEV_MAPS, OP_CONV3D = 1, 2, 3, 4, 5, 6, 7, 8
 OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, OP_FUSEUP, OP_RECORD, OP_WAIT = 12, 13, 14, 15, 16, 17, 18
 OP_KSUM = 11
+OP_STEM2 = 19
 OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS = 1, 2, 4
 
 

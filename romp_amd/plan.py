@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
-                  OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, RompOp)
+                  OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, OP_STEM2, RompOp)
 
 BN_EPS = 1e-5
 HEAD_IN_CH = 48          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 16 (the f16x2 kernels' channel chunk:
@@ -495,6 +495,9 @@ def stream_races(P):
         if seam_ds:                                              # the folded downsample: its input is read, its output never materialises
             r.append(ops[i - 2].in_buf)
         for o in srcs:
+            if o.kind == OP_STEM2:                               # reads the caller's image only (its in_buf names the tensor that no longer exists)
+                w += [o.out_buf] if o.out_buf >= 0 else []
+                continue
             r += [b for b in ((o.in_buf,) if (seam_ds and o is not op) else (o.in_buf, o.res_buf)) if b >= 0]
             if o.kind in (OP_FUSESUM, OP_FUSEUP):
                 r += [o.term_buf[k] for k in range(o.n_terms) if o.term_buf[k] >= 0]
@@ -589,6 +592,50 @@ def fuse_basic_blocks(P):
             P.bytes[i] = 0.0
             P.fused_blocks += 1
     return P.fused_blocks
+
+
+def fuse_stem2(P):
+    """Peephole (after assign_formats): HRNet's stem -- ROMP_OP_STEM 3 -> 64 (MFMA form, H2 output) followed by the 3x3 stride-2
+    64 -> 64 conv + BN + ReLU that is the only reader of its output (model.py:384-390) -- becomes ONE launch (csrc/stem2.hip): the
+    stem's op turns into ROMP_OP_NOP (fields intact: the kernel takes weights / BN from there), the conv into ROMP_OP_STEM2 with
+    its weights repacked per wave (pack_h2_wave16).  The 64-channel half-resolution tensor is never written or read: 2 x 16.8 MB
+    per image off the serial head of the graph.  Env ROMP_FUSE_STEM2=0: off (A/B runs).  -> 1 if fused."""
+    import os
+    P.fused_stem2 = 0
+    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_STEM2', '1') == '0' or len(P.ops) < 2:
+        return 0
+    a, b = P.ops[0], P.ops[1]
+    if not (a.kind == OP_STEM and b.kind == OP_CONV):
+        return 0
+    ok = (not (a.flags & OPF_STEM_VALU) and a.out_fmt == FMT_H2 and a.out_buf >= 0 and a.Cout == 64 and a.H % 64 == 0 and a.W % 64 == 0 and
+          b.in_buf == a.out_buf and (b.in_cstride, b.in_coff) == (a.out_cstride, a.out_coff) and b.ksize == 3 and b.stride == 2 and
+          b.groups == 1 and b.Cin == 64 and b.Cout == 64 and b.cin_pad == 64 and b.cout_pad == 64 and b.relu and b.relu_from == 0 and
+          b.res_buf < 0 and b.weight_h2 and b.scale_h2 and b.in_fmt == FMT_H2 and b.out_fmt == FMT_H2 and b.pad_h == -1 and b.pad_w == -1 and
+          b.out_rstride == 0 and b.out_bstride == 0 and b.out_buf >= 0 and (b.H, b.W) == (a.H // 2, a.W // 2) and a.stream == b.stream and
+          a.act_shift == b.act_shift and ((b.out_cstride | b.out_coff) & 7) == 0)
+    if not ok:
+        return 0
+    for j in range(2, len(P.ops)):                               # the stem's output must die in that conv: nobody else reads this live range
+        o = P.ops[j]
+        if o.kind in (OP_FORK, OP_JOIN, OP_RECORD, OP_WAIT):
+            continue
+        reads = [o.in_buf, o.res_buf] + [o.term_buf[k] for k in range(o.n_terms if o.kind in (OP_FUSESUM, OP_FUSEUP) else 0)]
+        if a.out_buf in reads:
+            return 0
+        if o.out_buf == a.out_buf and o.kind != OP_NOP:
+            break                                                  # (the buffer starts a new life)
+    by_ptr = {c.data_ptr(): c for c in P.consts if isinstance(c, torch.Tensor)}
+    t = pack_h2_wave16(by_ptr[b.weight_h2].view(9, 4, 2, 2, 64, 8))
+    P.consts.append(t)
+    b.weight_aux = t.data_ptr()
+    b.flags |= OPF_WAVE16
+    a.kind, b.kind = OP_NOP, OP_STEM2
+    P.flops[1] += P.flops[0]
+    P.flops[0] = 0.0
+    P.bytes[1] = 4.0 * (a.H * a.W * 3 + (b.H // 2) * (b.W // 2) * 64)      # the image in, y out
+    P.bytes[0] = 0.0
+    P.fused_stem2 = 1
+    return 1
 
 
 class Program:
@@ -881,6 +928,7 @@ class Program:
         must not see the fused ones."""
         if not getattr(self, '_lowered', False):
             assign_formats(self)
+            fuse_stem2(self)                 # (first: its reader analysis wants every op still a plain conv)
             fuse_basic_blocks(self)
             fuse_bottleneck_seams(self)
             fuse_up_sums(self)

@@ -377,6 +377,10 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM:
             written[op.out_buf] = op.out_fmt
+        elif op.kind == L.OP_STEM2:                           # the fused stem (round 6): reads the image, writes y in H2
+            assert op.out_fmt == L.FMT_H2 and (op.flags & L.OPF_WAVE16) and op.weight_aux and P.ops[0].kind == L.OP_NOP and op is P.ops[1], name
+            n_h2 += 1
+            written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_SEAM1X1:                         # fused Bottleneck seam: writes t (the NOP's output) and u, both H2
             assert op.in_fmt == L.FMT_H2 and op.out_fmt == L.FMT_H2, name
             n_h2 += 1
@@ -525,8 +529,14 @@ def test_hrnet_program_fusions_are_the_documented_ones(monkeypatch):
                 assert P.ops[i - 2].in_buf not in (P.ops[i - 1].out_buf, P.ops[i].out_buf)      # x0 is intact while the seam reads it
         assert sum(bool(o.flags & L.OPF_SEAM_DS) for o in P.ops) == getattr(P, 'folded_downsamples', 0)
         return ks.count(L.OP_BBLOCK32), ks.count(L.OP_BBLOCK64), ks.count(L.OP_SEAM1X1), ks.count(L.OP_FUSEUP), ks.count(L.OP_FUSESUM), ks.count(L.OP_NOP)
-    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_FUSEUP', 'ROMP_MERGE_S2', 'ROMP_SEAM_DS'):
+    for v in ('ROMP_FUSE_BLOCKS', 'ROMP_FUSE_SEAMS', 'ROMP_FUSEUP', 'ROMP_MERGE_S2', 'ROMP_SEAM_DS', 'ROMP_FUSE_STEM2'):
         monkeypatch.delenv(v, raising=False)
+    # round 6: the stem and conv2 are one launch (ROMP_OP_STEM2 behind the NOP that holds the stem): one more NOP in every lowering
+    P6 = build_romp_hrnet32(sd, 'cpu', 512, bf16x3='f16x2')
+    P6.op_array()
+    assert P6.fused_stem2 == 1 and [o.kind for o in P6.ops[:2]] == [L.OP_NOP, L.OP_STEM2] and P6.ops[0].in_buf == L.BUF_IMAGE
+    assert kinds() == (32, 32, 3, 16, 7, 67 + 18 + 1 + 1)
+    monkeypatch.setenv('ROMP_FUSE_STEM2', '0')
     # round 4: 16 of the 23 fuse-layer outputs have up-terms: each runs as FUSEUP and the 18 (merged) 1x1 up-convs become NOPs
     assert kinds() == (32, 32, 3, 16, 7, 67 + 18 + 1)
     assert kinds(split_k_items=256) == (32, 0, 0, 0, 23, 32)
@@ -566,7 +576,7 @@ def test_committed_variant_tables_resolve(cfg):
     convs = [n for n, o in zip(P.names, P.ops) if o.kind == L.OP_CONV]
     # every conv layer has an entry; an entry beyond that must name a layer a fusion has absorbed (a NOP today: layer1.0.downsample,
     # folded into the first seam in round 5 -- its entry keeps the ROMP_SEAM_DS=0 arm of an A/B run on the same table)
-    absorbed = {n for n, o in zip(P.names, P.ops) if o.kind == L.OP_NOP}
+    absorbed = {n for n, o in zip(P.names, P.ops) if o.kind in (L.OP_NOP, L.OP_STEM2)}       # (stem.conv2: inside ROMP_OP_STEM2 since round 6; ROMP_FUSE_STEM2=0 arm)
     assert set(convs) <= set(t['layers']) and set(t['layers']) - set(convs) <= absorbed, set(convs) ^ set(t['layers'])
     variants, why = tuning.resolve_table(types.SimpleNamespace(lib=L.load(), program=P), B, t['layers'])
     assert variants is not None, why

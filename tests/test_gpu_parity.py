@@ -934,6 +934,66 @@ def test_stem_mfma_vs_torch(dev, kernel, B, H, W):
     assert big.ops[0].flags & L.OPF_STEM_VALU, '256 |w| beyond fp16: the plan must pick the float32 stem'
 
 
+@pytest.mark.parametrize('B,H,W', [(1, 64, 64), (3, 128, 64), (2, 512, 512)])
+def test_stem2_fused_vs_torch(dev, B, H, W, monkeypatch):
+    """csrc/stem2.hip (round 6, ROMP_OP_STEM2): HRNet's stem and conv2 (model.py:384-390) as ONE kernel whose 64-channel
+    half-resolution intermediate never leaves the CU, against torch on the CPU (x / 255 * 2 - 1, conv 3x3 s2 3 -> 64 + BN + ReLU,
+    conv 3x3 s2 64 -> 64 + BN + ReLU; zero padding of BOTH convs at the image borders: every tile of the small sizes touches one)
+    and against the ROMP_FUSE_STEM2=0 lowering of the same program (two launches: the tensors agree to float32 rounding of the
+    intermediate's fp16 pieces, which the fused kernel forms the same way)."""
+    import ctypes as C
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, set_conv_math, decode_h2
+    g = torch.Generator().manual_seed(13 * B + H)
+    img = torch.rand(B, H, W, 3, generator=g) * 255.0
+    w1 = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / (64 * 9) ** 0.5
+    w3 = torch.randn(64, 64, 1, 1, generator=g) / 8.0
+    sc = [torch.rand(64, generator=g) + 0.5 for _ in range(3)]
+    sh = [torch.randn(64, generator=g) * 0.2 for _ in range(3)]
+    m = F.conv2d((img / 255.0 * 2.0 - 1.0).permute(0, 3, 1, 2), w1, None, stride=2, padding=1)
+    m = torch.relu(m * sc[0].view(1, -1, 1, 1) + sh[0].view(1, -1, 1, 1))
+    y = F.conv2d(m, w2, None, stride=2, padding=1)
+    ref = torch.relu(y * sc[1].view(1, -1, 1, 1) + sh[1].view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    lib = L.load()
+    outs = {}
+    for fuse in ('1', '0'):
+        monkeypatch.setenv('ROMP_FUSE_STEM2', fuse)
+        P = Program(dev)
+        set_conv_math(P, 'f16x2')
+        a = P.stem('stem.conv1', w1, sc[0], sh[0], H, W)
+        b = P.conv('stem.conv2', a, [w2], [sc[1]], [sh[1]], 3, 2, True)
+        P.conv('reader', b, [w3], [sc[2]], [sh[2]], 1, 1, True)          # (keeps conv2's output an H2 tensor with a consumer)
+        ops = P.op_array()
+        assert P.fused_stem2 == int(fuse) and [o.kind for o in P.ops[:2]] == ([L.OP_NOP, L.OP_STEM2] if fuse == '1' else [L.OP_STEM, L.OP_CONV])
+        h = C.c_void_p()
+        sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+        L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+        try:
+            dummy = torch.empty(16, device=dev)
+            xd = img.to(dev).contiguous()
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for graph in (0, 1):                                   # eagerly, and with the stem2 op as the eager prefix of a graph replay
+                    L.check(lib.romp_net_set_graph(h, graph))
+                    for rep in range(2):
+                        L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+                    n = P.buf_floats[b.buf] * B
+                    out = torch.empty(n, device=dev)
+                    L.check(lib.romp_net_read_buffer(h, b.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
+                    s.synchronize()
+                    got = decode_h2(out.cpu().reshape(B, H // 4, W // 4, 64))
+                    err = (got - ref).abs().max().item() / ref.abs().max().item()
+                    print(f'stem2 fuse={fuse} graph={graph} B={B} {H}x{W}: relative err {err:.3e}')
+                    assert err < 3e-5, (fuse, graph, err)
+                    outs[(fuse, graph)] = got
+        finally:
+            lib.romp_net_destroy(h)
+    assert torch.equal(outs[('1', 0)], outs[('1', 1)])
+    d = (outs[('1', 0)] - outs[('0', 0)]).abs().max().item()
+    assert d < 2e-5 * max(1.0, ref.abs().max().item()), d
+
+
 @pytest.mark.parametrize('max_batch', [1, 2])
 def test_net_conv_math_all_single_image(dev, max_batch, monkeypatch):
     """conv_math='all' in a single-image plan: every conv carries the bf16x3 pack in weight_aux, the
