@@ -15,8 +15,8 @@ import re
 import sys
 from collections import defaultdict
 
-NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|fuseup_kernel|stem_conv_kernel|stem_mfma_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
-FIRST = ('stem_conv_kernel', 'stem_mfma_kernel', 'stem7_conv_kernel')
+NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|fuseup_kernel|stem_conv_kernel|stem_mfma_kernel|stem2_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
+FIRST = ('stem_conv_kernel', 'stem_mfma_kernel', 'stem2_kernel', 'stem7_conv_kernel')
 
 
 def kernel_of(variant_name):
@@ -28,12 +28,18 @@ def kernel_of(variant_name):
         return ('seam1x1_kernel',)
     if variant_name == 'fuseup':
         return ('fuseup_kernel',)
-    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2s|h2k|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
+    if variant_name == 'stem2':
+        return ('stem2_kernel',)
+    if variant_name == 'seam1x1_ds':
+        return ('seam1x1_kernel<1',)
+    m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2s|h2k|h2g|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)
     if not m:
         return None
     fam, ks, s, mt, nt, tw, ck = m.groups()
     if fam == 'h2r':                                         # conv_h2r_kernel<P, NS, TW, KSUB>: ck = 16 * KSUB
         return 'conv_h2r_kernel<%s, %s, %s, %d>' % (mt, nt, tw, int(ck) // 16)
+    if fam == 'h2g':                                         # conv_h2g_kernel<KS, P, NS, TW, S, KSUB>: ck = 32 * KSUB
+        return 'conv_h2g_kernel<%s, %s, %s, %s, %s, %d>' % (ks, mt, nt, tw, s, int(ck) // 32)
     if fam == 'h2k':
         return 'conv_h2k_kernel<%s, %s, %s, %s>' % (ks, s, mt, tw)
     if fam in ('h2q', 'h2s'):

@@ -25,7 +25,7 @@ def overlap(trace):
             if NET.match(n):
                 rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), n))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2].startswith(('stem_mfma_kernel', 'stem_conv_kernel'))]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith(('stem_mfma_kernel', 'stem_conv_kernel', 'stem2_kernel'))]
     if len(starts) < 2:
         return None
     a, b = starts[-2], starts[-1]                       # the last complete forward
@@ -52,7 +52,7 @@ def main(cc, trace, counters):
             agg[n][row['Counter_Name']] += float(row['Counter_Value'])
             if row['Counter_Name'] == counters[0]:
                 cnt[n] += 1
-                forwards += n.startswith(('stem_mfma_kernel', 'stem_conv_kernel'))
+                forwards += n.startswith(('stem_mfma_kernel', 'stem_conv_kernel', 'stem2_kernel'))
     forwards = max(forwards, 1)
     ov = overlap(trace)
     print('# rocprofv3 --kernel-trace --pmc %s, default job, branch streams ON' % ' '.join(counters))

@@ -19,7 +19,7 @@ def main(path, skip=2):
         for r in csv.DictReader(f):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2].startswith(('stem_mfma_kernel', 'stem_conv_kernel'))]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith(('stem_mfma_kernel', 'stem_conv_kernel', 'stem2_kernel'))]
     if len(starts) < skip + 2:
         raise SystemExit('only %d forwards in the trace' % len(starts))
     spans = []
