@@ -591,7 +591,12 @@ int romp_net_forward(romp_net* n, const float* image, int B, float* center, floa
     if (B > n->max_batch) { set_error("batch %d > max_batch %d", B, n->max_batch); return ROMP_ECAPACITY; }
     hipStream_t st = (hipStream_t)stream;
     conv_set_sat_counter(n->sat, n->sat_checked);
-    if (!n->use_graph || n->mode != 0) return run_all(n, image, B, center, params, st);
+    // Streams off (the profiling configuration: every op on the caller's stream) replays EAGERLY even in graph mode.  A forward
+    // without branch streams is a single-chain hipGraph, and ROCm 7.x's packet-capture path for such graphs faults (GPU memory
+    // access fault, 3 of 6 runs) when the host calls hipDeviceSynchronize between replays of a short job -- gone with
+    // DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, with a stream synchronisation instead, without the graph, and with the multi-branch graphs
+    // every other configuration builds (profiles/r06_serial_graph_fault.txt: the bisect).  Not ours to fix; not worth a graph.
+    if (!n->use_graph || n->mode != 0 || !n->use_streams) return run_all(n, image, B, center, params, st);
     ROMP_REQUIRE(st != nullptr, "graph mode needs a non-default stream");
     // The stem is the only op that reads the caller's image: launched eagerly in front of the graph, the graph no longer
     // depends on WHERE the input lives (a caller streaming frames from ever new tensors replays one graph).
