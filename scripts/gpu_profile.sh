@@ -18,17 +18,17 @@ $BENCH --steps 2 --warmup 1 --no-roofline --dump-op-kernels "$OUT/op_kernels.jso
 grep -o '"variant_table": "[^"]*"' "$OUT/bench_plain.log" | head -1
 echo "tune pass exit $? :: $(grep -o '"value": [0-9.]*' "$OUT/bench_plain.log" | head -1)"
 if [ "${PROFILE_ONLY}" != "pmc" ]; then
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/bench_under_rocprof.log" 2>&1
 echo "stats pass exit $?"
 find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 # same command with the HRNet branches serialised on one stream: per-kernel durations without the
 # overlap of concurrent branch kernels -- these are the ones bench.py's roofline (serial per-op HIP events) must agree with
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats1 -o stats -- $BENCH --steps 5 --warmup 2 --streams 0 > "$OUT/bench_under_rocprof_serial.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats1 -o stats -- $BENCH --steps 5 --warmup 2 --streams 0 > "$OUT/bench_under_rocprof_serial.log" 2>&1
 echo "serial stats pass exit $?"
 find /tmp/rp_stats1 -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_serial.csv" \;
 fi
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/rp_$C -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$C.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/rp_$C -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$C.log" 2>&1
   echo "pmc $C exit $?"
   f=$(find /tmp/rp_$C -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python "$REPO/scripts/summarize_pmc.py" "$f" $C > "$OUT/pmc_${C}_by_kernel.csv" && cp "$f" /tmp/pmc_$C.csv
@@ -39,7 +39,7 @@ done
 for CS in "MfmaUtil LdsUtil LdsBankConflict" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   TAG=$(echo $CS | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/rp_multi
-  timeout 900 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/rp_multi -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$TAG.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/rp_multi -o pmc -- $BENCH --steps 1 --warmup 1 --no-roofline --streams 0 > "$OUT/pmc_$TAG.log" 2>&1
   echo "pmc $TAG exit $?"
   f=$(find /tmp/rp_multi -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" $CS > "$OUT/pmc_${TAG}_by_kernel.csv" <<'PY'
@@ -62,11 +62,11 @@ grep '^{' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/bench_under_rocprof.j
 grep '^{' "$OUT/bench_under_rocprof_serial.log" | tail -1 > "$OUT/bench_under_rocprof_serial.json"
 # the other workloads: kernel-trace stats only
 if [ -z "${BENCH_ARGS}" ]; then
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_smpl -o stats -- python $REPO/bench.py --workload smpl --no-cpu-baseline > "$OUT/bench_smpl_under_rocprof.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_smpl -o stats -- python $REPO/bench.py --workload smpl --no-cpu-baseline > "$OUT/bench_smpl_under_rocprof.log" 2>&1
   find /tmp/rp_smpl -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_smpl.csv" \;
   rm -f /tmp/romp_tune_bev.json
   python $REPO/bench.py --workload bev --no-cpu-baseline --no-roofline --steps 2 --warmup 1 --tune-file /tmp/romp_tune_bev.json > "$OUT/bench_bev_plain.log" 2>&1
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bev -o stats -- python $REPO/bench.py --workload bev --no-cpu-baseline --steps 5 --warmup 2 --tune-file /tmp/romp_tune_bev.json > "$OUT/bench_bev_under_rocprof.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bev -o stats -- python $REPO/bench.py --workload bev --no-cpu-baseline --steps 5 --warmup 2 --tune-file /tmp/romp_tune_bev.json > "$OUT/bench_bev_under_rocprof.log" 2>&1
   find /tmp/rp_bev -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bev.csv" \;
   grep '^{' "$OUT/bench_bev_under_rocprof.log" | tail -1 > "$OUT/bench_bev_under_rocprof.json"
   head -8 "$OUT/kernel_stats_smpl.csv"; head -12 "$OUT/kernel_stats_bev.csv"

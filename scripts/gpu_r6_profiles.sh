@@ -13,7 +13,7 @@ for W in bev resnet50 b128; do cp gpurun_out/prof_$W/pmc_traffic_by_op.json prof
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-f32-companion --no-parity --no-end-to-end --no-latency --no-roofline"
 rm -rf /tmp/rp_tl
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_tl -o tl -- $BENCH --global-batch 256 --steps 2 --warmup 1 > $REPO/gpurun_out/r06_trace_run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_tl -o tl -- $BENCH --global-batch 256 --steps 2 --warmup 1 > $REPO/gpurun_out/r06_trace_run.log 2>&1
 echo "== batch trace exit $? :: $(grep -o '"value": [0-9.]*' $REPO/gpurun_out/r06_trace_run.log | head -1)"
 f=$(find /tmp/rp_tl -name "*kernel_trace.csv" | head -1)
 python $REPO/scripts/timeline.py "$f" 4 | tee $REPO/gpurun_out/r06_timeline_b32.txt | head -12
