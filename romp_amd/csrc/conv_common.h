@@ -43,6 +43,8 @@ struct ConvParams {
     int relu_from;            // relu != 0: ReLU on output channels >= relu_from only (romp_op.relu_from; a multiple of 32)
     int* sat;                 // saturation counter of the running net (conv_sat_counter(), may be nullptr): +1 per wave and work item that
                               // clamped a value at +-65504 while splitting it into fp16 pieces (h2_sat): out-of-calibration activations
+    int run_len;              // (fused block kernel, strip form) vertically consecutive tiles per run: a work item is a RUN, its tiles hand two
+                              // rows of the intermediate on to each other (conv_h2c.h); tiles_y % run_len == 0
     int dbg;                  // ablation switches, env ROMP_CONV_DEBUG (timing experiments only: outputs are wrong).
                               // bits: 1 skip global loads / DMA, 2 skip LDS staging writes, 4 skip epilogue, 8 skip MFMA loop,
                               // 512 (h2r / h2s, correct outputs) the LDS-transposed epilogue instead of the direct one,

@@ -36,7 +36,7 @@ namespace romp {
 // wave).  C = 32 (the two-waves-per-SIMD form of the 32-channel block): two channel groups x two ROW groups -- wave (cg, t) does
 // m rows 5 t .. 5 t + 4 of conv1 and output rows 4 t .. 4 t + 3 of conv2 -- 144 weight registers per wave, 71 KB of LDS: two
 // workgroups per CU, each other's MFMAs covering each other's side work.
-template <int C>
+template <int C, bool STRIP = false>
 struct RCfg {
     static constexpr int TH = 8, TW = 16;
     static constexpr int IR = TH + 4, IC = TW + 4;             // input halo 12 x 20
@@ -46,9 +46,15 @@ struct RCfg {
     static constexpr int NPL = C / 4;                          // planes: C / 8 octets x {high, low}; plane = 2 * octet + piece
     static constexpr int NKC = C / 32;                         // 32-input-channel chunks (one MFMA's K)
     static constexpr int NCG = C / 16, NRG = 4 / NCG;          // channel groups of 16 output channels; row groups
-    static constexpr int MRW = MR / NRG, THW = TH / NRG;       // m rows / output rows per wave
+    // STRIP (round 6, the halo-carrying form): a workgroup walks RUNS of vertically consecutive tiles; m rows 8, 9 of a tile ARE m rows
+    // 0, 1 of the tile below it, so every tile but a run's first copies them (LDS to LDS) and its conv1 produces m rows R0 = 2 .. 9 only,
+    // from input rows 2 .. 11: 8 rows of 16 + ONE edge block (rows 2 .. 9 x columns {0, 17}: all 16 lanes of it used) instead of 10 + 2.
+    // A run's first tile computes m rows 0, 1 and their four edge pixels in a plain prologue in front of the same main loop.
+    static constexpr int R0 = STRIP ? 2 : 0;                   // first m row (= first input row) of the main conv1
+    static constexpr int MRT = STRIP ? TH : MR;                // m rows the main conv1 produces
+    static constexpr int MRW = MRT / NRG, THW = TH / NRG;      // m rows / output rows per wave
     static constexpr int IRW = MRW + 2, MRW2 = THW + 2;        // input rows a wave walks in conv1; m rows in conv2
-    static constexpr int NEB = 2 / NRG;                        // edge blocks per wave
+    static constexpr int NEB = STRIP ? 1 : 2 / NRG;            // edge blocks per wave (STRIP, C = 32: row group 0's waves only)
     static constexpr int NPIECE = NPL * XPL / 64;              // DMA pieces (64 units): 60 / 30
     static constexpr int NI = (NPIECE + 3) / 4;                // per wave: 15 / 8 (the last one only for waves 0, 1 when C = 32)
     static constexpr int OFF_M = NPL * XPL * 16;
@@ -68,9 +74,9 @@ typedef float f32x4c __attribute__((ext_vector_type(4)));
 // five more copies of a fully unrolled kernel are most of this file's compile time.  The product kernel (DBG = 0) ALWAYS counts the
 // values it clamps at +-65504 on their way into fp16 pieces (round 6: conv_common.h sat_track_pk, one v_pk_maximum3_f16 per four
 // values; rounds 4-5 had a separate "checked" instantiation that cost 1.7-2 % of the job, profiles/r06_guard_cost*.txt)
-template <int C, int DBG>
+template <int C, int DBG, bool STRIP = false>
 __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvParams p) {
-    using X = RCfg<C>;
+    using X = RCfg<C, STRIP>;
     using frag = f16x8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sBuf = reinterpret_cast<char*>(smem);
@@ -88,8 +94,22 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
     const int nwg_q = gridDim.x / p.n_queues;
     const int j0 = blockIdx.x / p.n_queues;
     if (j0 >= p.per_queue) return;
-    const int n_mine = (p.per_queue - j0 + nwg_q - 1) / nwg_q;
-    auto tile_of = [&](int k) __attribute__((always_inline)) { return decode_item(p, qx, j0 + k * nwg_q, 32); };
+    // work items: tiles (every nwg_q-th of the queue), or -- STRIP -- RUNS of run_len vertically consecutive tiles: item t of the
+    // queue's contiguous range is (image, segment of the column, tile column), tile columns fastest (the workgroups of an XCD work
+    // on neighbouring columns of the same rows at the same time)
+    const int n_items = (p.per_queue - j0 + nwg_q - 1) / nwg_q;
+    const int n_mine = STRIP ? n_items * p.run_len : n_items;
+    const int segs = STRIP ? p.tiles_y / p.run_len : 1;
+    auto tile_of = [&](int k, int run, int kr) __attribute__((always_inline)) {
+        if (!STRIP) return decode_item(p, qx, j0 + k * nwg_q, 32);
+        int t = qx * p.per_queue + j0 + run * nwg_q;
+        Item r;
+        r.g = 0; r.n0 = 0;
+        r.tx = t % p.tiles_x; t /= p.tiles_x;
+        r.ty = (t % segs) * p.run_len + kr;
+        r.b = t / segs;
+        return r;
+    };
 
     // scale / shift of this lane's 4 channels (16 wv + 4 q ..), PRE-MULTIPLIED by 2^act_shift: m and y are produced in the scaled
     // domain the H2 pieces live in (ReLU commutes with the positive factor; the residual's pieces are x * 2^act_shift already)
@@ -103,14 +123,19 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 
     // ---- halo DMA: piece 4 k + wv is this wave's k-th; a lane's unit U = 64 piece + lane -> plane U / 240, pixel U % 240
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr bool PACKED = STRIP && C == 32;
     int d_rc[X::NI], d_off[X::NI];                             // row | col << 8;  byte offset from the halo origin
 #pragma unroll
     for (int k = 0; k < X::NI; ++k) {
         const int U = (k * 4 + wv) * 64 + lane;
         const int plane = U / X::XPL, r = U % X::XPL;
         const int row = r / X::IC, col = r % X::IC;
-        d_rc[k] = row | (col << 8);
-        d_off[k] = ((row * p.W + col) * p.in_cs + (plane >> 1) * 8 + (plane & 1) * 4) * 4;
+        // (PACKED, the 32-channel strip form: ONE register per piece -- row | col << 8 | plane << 16 -- and the offset re-derived at each
+        // use, ~8 full-rate VALU a piece under conv2's MFMAs: at 128 + 128 registers the kernel otherwise reloads spilled table entries
+        // between its DMA pieces and waits on each for the piece before it to land.  The 64-channel form keeps the table: with
+        // v_mul_lo_u32 -- quarter rate -- the re-derivation cost its conv2 8 %, profiles/r06s_trace.txt)
+        d_rc[k] = row | (col << 8) | (PACKED ? plane << 16 : 0);
+        d_off[k] = PACKED ? 0 : ((row * p.W + col) * p.in_cs + (plane >> 1) * 8 + (plane & 1) * 4) * 4;
     }
     i32x4_t rsrc;                                              // the input tensor as a raw buffer: offsets beyond num_records read zeros
     {
@@ -121,19 +146,31 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
         rsrc[3] = 0x00020000;
     }
     auto is_interior = [&](const Item& it) __attribute__((always_inline)) { return it.ty > 0 && it.ty < p.tiles_y - 1 && it.tx > 0 && it.tx < p.tiles_x - 1; };
-    auto fetch_piece = [&](const Item& it, bool valid, bool interior, int kk) __attribute__((always_inline)) {
+    auto fetch_piece = [&](const Item& it, bool valid, bool interior, bool first, int kk) __attribute__((always_inline)) {
         if (DBG & 1) return;
         if (!valid || kk * 4 + wv >= X::NPIECE) return;        // (uniform)
         const int iy0 = it.ty * X::TH - 2, ix0 = it.tx * X::TW - 2;
         const int origin = ((it.b * p.H + iy0) * p.W + ix0) * p.in_cs * 4;     // may be "negative": the sum with d_off is not
         const unsigned dst = lds0 + (unsigned)((kk * 4 + wv) * 1024);
         int voff = d_off[kk] + origin;
+        if (PACKED) {
+            int rc = d_rc[kk];
+            asm volatile("" : "+v"(rc));
+            const unsigned row = rc & 255, col = (rc >> 8) & 255, plane = (unsigned)rc >> 16;
+            const unsigned pix = __umul24(row, (unsigned)p.W) + col;           // (v_mad_u32_u24: every factor far below 2^24)
+            voff = (int)((__umul24(pix, (unsigned)p.in_cs) + (plane >> 1) * 8 + (plane & 1) * 4) * 4) + origin;
+        }
         if (!interior) {
             int rc = d_rc[kk];
             asm volatile("" : "+v"(rc));
-            const int iy = iy0 + (rc & 255), ix = ix0 + (rc >> 8);
+            const int iy = iy0 + (rc & 255), ix = ix0 + ((rc >> 8) & 255);
             const int ok = (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
             voff = ok ? voff : (int)0x80000000;
+        }
+        if (STRIP && !first) {                                 // a carrying tile starts at input row 2: rows 0, 1 are not fetched (zeros land)
+            int rc = d_rc[kk];
+            asm volatile("" : "+v"(rc));
+            voff = (rc & 255) >= 2 ? voff : (int)0x80000000;
         }
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(dst) : "memory");
     };
@@ -141,24 +178,24 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
     // ---- LDS addresses (bytes).  Input plane unit (plane, row, col) = plane * 240 + row * 20 + col; m: OFF_M + plane * 192 + row * 18 + col
     // fragment of a row block: lane (px, q) reads octet 4 kc + q, piece pc of the pixel dx columns right of its own: base + immediates
     // (conv1's blocks are m columns 1..16 = input columns 1 + px + dx; conv2's are output columns px = m columns px + dx)
-    const int xa = (2 * q * X::XPL + tg * X::MRW * X::IC + 1 + px) * 16;   // + ((8 kc + pc) * 240 + Rl * 20 + dx) * 16, Rl: the wave's local row
+    const int xa = (2 * q * X::XPL + (X::R0 + tg * X::MRW) * X::IC + 1 + px) * 16;   // + ((8 kc + pc) * 240 + Rl * 20 + dx) * 16, Rl: the wave's local row
     const int ma = X::OFF_M + (2 * q * X::MPL + tg * X::THW * X::MC + px) * 16;   // + ((8 kc + pc) * 192 + Rl * 18 + dx) * 16
     // the two edge blocks of conv1: m pixels (row, col in {0, 17}); E0 rows 0..7 (lane px -> row px / 2, col 17 (px & 1)), E1 rows 8, 9 (px < 4)
     const int e_row = px >> 1, e_col = (px & 1) * 17;
     const bool e1_act = px < 4;
-    const int xe0 = (2 * q * X::XPL + e_row * X::IC + e_col) * 16;                         // + ((8 kc + pc) * 240 + dy * 20 + dx) * 16
+    const int xe0 = (2 * q * X::XPL + (X::R0 + e_row) * X::IC + e_col) * 16;               // + ((8 kc + pc) * 240 + dy * 20 + dx) * 16  (STRIP: THE edge block, m rows 2 .. 9)
     const int xe1 = (2 * q * X::XPL + (e1_act ? 8 + e_row : 8) * X::IC + (e1_act ? e_col : 0)) * 16;
     // hand-over stores: lane (px, q) holds channels 16 wv + 4 q .. + 3 = half (q & 1) of octet 2 wv + q / 2
     const int mo = 2 * cg + (q >> 1);
-    const int hs = X::OFF_M + (2 * mo * X::MPL + tg * X::MRW * X::MC + 1 + px) * 16 + (q & 1) * 8;   // row block: + (pc * 192 + rl * 18) * 16
-    const int hse0 = X::OFF_M + (2 * mo * X::MPL + e_row * X::MC + e_col) * 16 + (q & 1) * 8;   // + pc * 192 * 16  (E1: + 8 * 18 * 16)
+    const int hs = X::OFF_M + (2 * mo * X::MPL + (X::R0 + tg * X::MRW) * X::MC + 1 + px) * 16 + (q & 1) * 8;   // row block: + (pc * 192 + rl * 18) * 16
+    const int hse0 = X::OFF_M + (2 * mo * X::MPL + (X::R0 + e_row) * X::MC + e_col) * 16 + (q & 1) * 8;   // + pc * 192 * 16  (E1: + 8 * 18 * 16)
     // the residual x of output pixel (r, px) in the input halo: pixel (r + 2, px + 2), same octet half
     const int ra = (2 * mo * X::XPL + (2 + tg * X::THW) * X::IC + 2 + px) * 16 + (q & 1) * 8;   // + (pc * 240 + rl * 20) * 16
     char* sR = sBuf + X::OFF_R + (wv * 2 * X::THW * 64 + lane) * 8;   // this lane's parking slots: + (rl * 2 + pc) * 512
 
-    Item it = tile_of(0);
+    Item it = tile_of(0, 0, 0);
 #pragma unroll
-    for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, kk);
+    for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, true, kk);
     // ---- this wave's weights (asked for AFTER the first halo: both trips overlap): 16 output channels x 64 input channels x 9 taps x 2 pieces of each conv
     frag w1[9][X::NKC][2], w2[9][X::NKC][2];                   // [tap][k-chunk of 32 input channels][piece]
 #pragma unroll
@@ -194,10 +231,14 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
     f32x4c acc2[X::THW];                                        // (the last row's outlives its tile: finished under the next tile's first MFMAs)
     unsigned sat_pk = 0u;                                       // per-half maximum of the high pieces formed: a half == 0x7BFF iff a value was clamped (conv_common.h sat_track_pk)
     Item itp = it;
+    int run = 0, kr = 0;                                       // (STRIP) this tile's run and its place in it
 #pragma unroll 1
     for (int k = 0; k < n_mine; ++k) {
         const bool has_next = k + 1 < n_mine;
-        const Item itn = has_next ? tile_of(k + 1) : it;
+        const bool first = !STRIP || kr == 0;                  // (STRIP) a run's first tile: no m rows to take over
+        const int kr_n = STRIP ? (kr + 1 == p.run_len ? 0 : kr + 1) : 0, run_n = STRIP ? run + (kr_n == 0) : 0;
+        const bool next_first = !STRIP || kr_n == 0;
+        const Item itn = has_next ? tile_of(k + 1, run_n, kr_n) : it;
         const bool next_interior = is_interior(itn);
 
         // ---- the finish of an output row: bn2 + x + ReLU in the scaled domain, split; lanes (px, q) and (px, q ^ 1) trade halves
@@ -273,7 +314,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
             default: if (act) *reinterpret_cast<uint2*>(sBuf + addr + X::MPL * 16) = make_uint2(hl[0], hl[1]); break;
             }
         };
-        const int iy_m0 = it.ty * X::TH - 1 + tg * X::MRW;     // image row of this wave's m row 0
+        const int iy_m0 = it.ty * X::TH - 1 + X::R0 + tg * X::MRW;   // image row of this wave's first m row
         // this wave's edge block(s): block e covers m rows 8 e + (px >> 1) (e = 1: lanes px < 4 only), columns {0, 17}
         auto edge_no = [&](int i) __attribute__((always_inline)) { return X::NEB == 2 ? i : tg; };   // (uniform)
         const int ix_e = it.tx * X::TW - 1 + e_col;             // image column of this lane's edge-block pixel
@@ -288,7 +329,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
         for (int r = 0; r < X::MRW; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc1[r][i] = 0.f;
-        {
+        if constexpr (!STRIP) {
             // fragment reads run PF units (a unit = the MFMAs fed by one fragment pair) ahead of their MFMAs.  Units 0 .. NUE - 1: the
             // edge block(s), unit (tap * NKC + kc) * NEB + e; then the row-block fragments of the wave's input rows,
             // NUE + ((Rl * 3 + dx) * NKC + kc)
@@ -387,6 +428,221 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #pragma unroll
             for (int t = 0; t < HAND_N; ++t) hand_micro(acc1[X::MRW - 1], (unsigned)(iy_m0 + X::MRW - 1) < (unsigned)p.Ho, true, hs + (X::MRW - 1) * X::MC * 16, t);
             ROMP_TRACE(13);
+        } else {
+            // ======== the halo-carrying form (RCfg): prologue (a run's first tile) or copies (the others), ONE edge block, m rows 2 .. 9
+            // units (a unit = the MFMAs fed by one fragment pair, read PF units ahead): 0 .. NUE - 1 the edge block's, tap * NKC + kc; then
+            // the row units NUE + (Rl * 3 + dx) * NKC + kc.  NAP: accumulators of a block without row reuse (C = 64, one wave per SIMD: one
+            // per product, consecutive MFMAs independent; C = 32: the SIMD's other wave fills the gaps, registers are short)
+            constexpr int PF = C == 32 ? 2 : 3, NUE = 9 * X::NKC, NU = NUE + X::IRW * 3 * X::NKC, NAP = C == 32 ? 1 : 3;
+            const bool do_edge = X::NRG == 1 || tg == 0;       // (uniform) C = 32: the edge block belongs to row group 0's waves
+            // ---- 0. a run's first tile: m rows 0, 1 (C = 32: row `tg`) and their four edge pixels (C = 32: row group 1's waves), written
+            // plainly (once per run; no side work to place: the tile's own side work rides under the edge block and the rows below)
+            if (first) {
+                constexpr int PRW = 2 / X::NRG;                // prologue rows per wave
+                // (addresses derived HERE from the main loop's bases, behind an opaque copy: hoisted out of the tile loop they cost the
+                // 32-channel kernel, 128 + 128 registers at two waves per SIMD, spills of its DMA tables)
+                int xp = xa, hp = hs;
+                asm volatile("" : "+v"(xp), "+v"(hp));
+                xp += (tg * PRW - (X::R0 + tg * X::MRW)) * X::IC * 16;
+                hp += (tg * PRW - (X::R0 + tg * X::MRW)) * X::MC * 16;
+                int xq = xe0, hq = hse0;                      // the main edge block's pixel (R0 + e_row, e_col) -> (e_row, e_col): lanes px < 4 are m rows 0, 1
+                asm volatile("" : "+v"(xq), "+v"(hq));
+                xq -= X::R0 * X::IC * 16;
+                hq -= X::R0 * X::MC * 16;
+                // units: (input row Ri, dx, kc) of the row blocks, then (tap, kc) of the edge pixels' block (C = 32: both row groups' waves
+                // compute it -- no divergent schedule -- row group 1's hand it over); fragments one unit ahead, pinned unit by unit
+                // (scheduled freely every fragment read goes first: 100 registers)
+                constexpr int NPR = (PRW + 2) * 3 * X::NKC, NP = NPR + 9 * X::NKC;
+                f32x4c ap[PRW][NAP], ae[NAP];
+#pragma unroll
+                for (int pr = 0; pr < NAP; ++pr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ae[pr][i] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < PRW; ++r)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ap[r][pr][i] = 0.f;
+                }
+                frag xb[2][2];
+                auto read_p = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        if (u < NPR) {
+                            const int Ri = u / (3 * X::NKC), dx = (u / X::NKC) % 3, kc = u % X::NKC;
+                            xb[u & 1][pc] = *reinterpret_cast<const frag*>(sBuf + xp + ((8 * kc + pc) * X::XPL + Ri * X::IC + dx) * 16);
+                        } else {
+                            const int kc = (u - NPR) % X::NKC, tap = (u - NPR) / X::NKC;
+                            xb[u & 1][pc] = *reinterpret_cast<const frag*>(sBuf + xq + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
+                        }
+                    }
+                };
+                read_p(0);
+                SIDE_PIN();
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    if (u + 1 < NP) read_p(u + 1);
+                    const frag (&x)[2] = xb[u & 1];
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        if (u < NPR) {
+                            const int Ri = u / (3 * X::NKC), dx = (u / X::NKC) % 3, kc = u % X::NKC;
+#pragma unroll
+                            for (int r = 0; r < PRW; ++r) {
+                                const int dy = Ri - r;
+                                if (dy >= 0 && dy <= 2)
+                                    ap[r][pr % NAP] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[dy * 3 + dx][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], ap[r][pr % NAP], 0, 0, 0);
+                            }
+                        } else {
+                            const int kc = (u - NPR) % X::NKC, tap = (u - NPR) / X::NKC;
+                            ae[pr % NAP] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], ae[pr % NAP], 0, 0, 0);
+                        }
+                    }
+                    SIDE_PIN();
+                }
+#pragma unroll
+                for (int r = 0; r < PRW; ++r) {
+                    f32x4c a = ap[r][0];
+#pragma unroll
+                    for (int pr = 1; pr < NAP; ++pr)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i] += ap[r][pr][i];
+#pragma unroll
+                    for (int t = 0; t < HAND_N; ++t)
+                        hand_micro(a, (unsigned)(it.ty * X::TH - 1 + tg * PRW + r) < (unsigned)p.Ho, true, hp + r * X::MC * 16, t);
+                    SIDE_PIN();
+                }
+                {
+                    f32x4c a = ae[0];
+#pragma unroll
+                    for (int pr = 1; pr < NAP; ++pr)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i] += ae[pr][i];
+                    const bool mine = e1_act && (X::NRG == 1 || tg == 1);
+                    const bool in = (unsigned)(it.ty * X::TH - 1 + e_row) < (unsigned)p.Ho && (unsigned)ix_e < (unsigned)p.Wo;
+#pragma unroll
+                    for (int t = 0; t < HAND_N; ++t)
+                        hand_micro(a, in, mine, hq, t);
+                    SIDE_PIN();
+                }
+            }
+            // ---- the take-over of m rows 8, 9 as rows 0, 1 (every tile but a run's first), each wave the units it hands over itself
+            // further down (its channel group's 4 planes): LDS operations of a wave execute in order, no barrier.  Interior: 4 planes x 2
+            // rows x columns 1 .. 16 = 128 units, two per lane (C = 32: by row group 1's waves, who produce rows 6 .. 9); the edge
+            // columns: 16 units, lanes 0 .. 15 of the wave that owns the edge block
+            // unit addresses: interior  OFF_M + ((4 cg + (lane >> 5)) * 192 + (8 + ((lane >> 4) & 1)) * 18 + 1 + (lane & 15)) * 16, the second unit 2
+            // planes on; edge  OFF_M + ((4 cg + (lane >> 2)) * 192 + (8 + ((lane >> 1) & 1)) * 18 + 17 * (lane & 1)) * 16  (computed in the step)
+            // ONE step under one uniform branch, reads then writes: a value that lives across the conditional steps of a schedule this
+            // tight was spilled to scratch (and came back behind an s_waitcnt vmcnt(0)); the step's LDS round trip is exposed, once a tile
+            constexpr int CP_UP = 8 * X::MC * 16;
+            auto copy_step = [&](bool interior, bool edge) __attribute__((always_inline)) {
+                if (first) return;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int cpI = X::OFF_M + ((4 * cg + (ln >> 5)) * X::MPL + (8 + ((ln >> 4) & 1)) * X::MC + 1 + (ln & 15)) * 16;
+                const int cpE = X::OFF_M + ((4 * cg + ((ln >> 2) & 3)) * X::MPL + (8 + ((ln >> 1) & 1)) * X::MC + 17 * (ln & 1)) * 16;
+                uint4 c0, c1, ce;
+                if (interior) {
+                    c0 = *reinterpret_cast<const uint4*>(sBuf + cpI);
+                    c1 = *reinterpret_cast<const uint4*>(sBuf + cpI + 2 * X::MPL * 16);
+                }
+                if (edge && lane < 16) ce = *reinterpret_cast<const uint4*>(sBuf + cpE);
+                if (interior) {
+                    *reinterpret_cast<uint4*>(sBuf + cpI - CP_UP) = c0;
+                    *reinterpret_cast<uint4*>(sBuf + cpI + 2 * X::MPL * 16 - CP_UP) = c1;
+                }
+                if (edge && lane < 16) *reinterpret_cast<uint4*>(sBuf + cpE - CP_UP) = ce;
+            };
+            constexpr int NSE = FIN_N + PARK_N + 1;
+            auto edge_side = [&](int t) __attribute__((always_inline)) {
+                if (t < FIN_N) fin_micro(itp, k > 0, X::THW - 1, t);
+                else if (t < FIN_N + PARK_N) park_micro(t - FIN_N);
+                else copy_step(X::NRG == 1 || tg == 1, do_edge);
+            };
+            frag xf[PF + 1][2];
+            auto read_x = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    if (u < NUE) {
+                        const int kc = u % X::NKC, tap = u / X::NKC;
+                        xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + xe0 + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
+                    } else {
+                        const int v = u - NUE, Rl = v / (3 * X::NKC), dx = (v / X::NKC) % 3, kc = v % X::NKC;
+                        xf[u % (PF + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + xa + ((8 * kc + pc) * X::XPL + Rl * X::IC + dx) * 16);
+                    }
+                }
+            };
+            // ---- (a) the edge block.  Under it: the previous tile's last output row, this tile's residual parking, the copies
+            f32x4c accP[NAP];
+#pragma unroll
+            for (int pr = 0; pr < NAP; ++pr)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accP[pr][i] = 0.f;
+            {
+                constexpr int GE = NUE * 3;
+#pragma unroll
+                for (int u = 0; u < PF; ++u) read_x(u);
+#pragma unroll
+                for (int u = 0; u < NUE; ++u) {
+                    const int kc = u % X::NKC, tap = u / X::NKC;
+                    read_x(u + PF);
+                    const frag (&x)[2] = xf[u % (PF + 1)];
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr) {
+                        accP[pr % NAP] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], accP[pr % NAP], 0, 0, 0);
+                        int lo, hi;
+                        share(u * 3 + pr, GE, NSE, lo, hi);
+#pragma unroll
+                        for (int t = lo; t < hi; ++t) edge_side(t);
+                        SIDE_PIN();
+                    }
+                }
+            }
+            // ---- (b) the row blocks, input row after input row.  Under input row 0: the edge block's hand-over; under row Rl >= 3: m row Rl - 3
+            const bool in_e = (unsigned)(it.ty * X::TH - 1 + X::R0 + e_row) < (unsigned)p.Ho && (unsigned)ix_e < (unsigned)p.Wo;
+#pragma unroll
+            for (int Rl = 0; Rl < X::IRW; ++Rl) {
+                const int dy_lo = Rl - (X::MRW - 1) > 0 ? Rl - (X::MRW - 1) : 0, dy_hi = Rl < 2 ? Rl : 2;     // m rows Rl - dy in [0, MRW)
+                const int nv = dy_hi - dy_lo + 1;
+                const int G = 3 * X::NKC * nv * 3;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int kc = 0; kc < X::NKC; ++kc) {
+                        const int u = NUE + (Rl * 3 + dx) * X::NKC + kc;
+                        if (u + PF < NU) read_x(u + PF);
+                        const frag (&x)[2] = xf[u % (PF + 1)];
+#pragma unroll
+                        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                            for (int dy = dy_lo; dy <= dy_hi; ++dy) {
+                                const int tap = dy * 3 + dx;
+                                acc1[Rl - dy] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[tap][kc][pr == 0 ? 1 : 0], x[pr == 1 ? 1 : 0], acc1[Rl - dy], 0, 0, 0);
+                                const int g = (((dx * X::NKC + kc) * 3) + pr) * nv + (dy - dy_lo);
+                                int lo, hi;
+                                share(g, G, HAND_N, lo, hi);
+#pragma unroll
+                                for (int t = lo; t < hi; ++t) {
+                                    if (Rl == 0) {
+                                        if (t == 0) {
+#pragma unroll
+                                            for (int pr = 1; pr < NAP; ++pr)
+#pragma unroll
+                                                for (int i = 0; i < 4; ++i) accP[0][i] += accP[pr][i];
+                                        }
+                                        hand_micro(accP[0], in_e, do_edge, hse0, t);
+                                    } else if (Rl >= 3) {
+                                        const int rl = Rl - 3;
+                                        hand_micro(acc1[rl], rl == 0 ? iy_m0 >= 0 : true, true, hs + rl * X::MC * 16, t);
+                                    }
+                                }
+                                SIDE_PIN();
+                            }
+                    }
+            }
+            ROMP_TRACE(11);
+#pragma unroll
+            for (int t = 0; t < HAND_N; ++t) hand_micro(acc1[X::MRW - 1], (unsigned)(iy_m0 + X::MRW - 1) < (unsigned)p.Ho, true, hs + (X::MRW - 1) * X::MC * 16, t);
+            ROMP_TRACE(13);
         }
         // ---- 2. every wave is done with the input halo and m is complete
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -438,7 +694,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
                             share(g, G, NS, lo, hi);
 #pragma unroll
                             for (int t = lo; t < hi; ++t) {
-                                if (t < f_hi - f_lo) fetch_piece(itn, has_next, next_interior, f_lo + t);
+                                if (t < f_hi - f_lo) fetch_piece(itn, has_next, next_interior, next_first, f_lo + t);
                                 else fin_micro(it, true, Rl - 3, t - (f_hi - f_lo));
                             }
                             SIDE_PIN();
@@ -469,6 +725,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
         ROMP_TRACE(15);
         itp = it;
         it = itn;
+        run = run_n; kr = kr_n;
     }
     if (!(DBG & 4)) {                                          // the last tile's last output row
         const int r = X::THW - 1;
@@ -513,6 +770,7 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     static int num_cu = 256;
     using KernelFn = void (*)(ConvParams);
     static KernelFn fn = bblockr_kernel<C, 0>;
+    static KernelFn fn_strip = bblockr_kernel<C, 0, true>;
     if (!attr) {                                               // (romp_net_create calls this path's set-up outside any stream capture)
 #ifdef ROMP_BBLOCK_KNOCKOUTS
         const char* e = getenv("ROMP_CONV_DEBUG");
@@ -527,6 +785,7 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
         }
 #endif
         ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
+        ROMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn_strip), hipFuncAttributeMaxDynamicSharedMemorySize, X::LDS_BYTES));
         int dev = 0;
         hipDeviceProp_t prop;
         ROMP_HIP_CHECK(hipGetDevice(&dev));
@@ -568,10 +827,40 @@ static int launch_bblockr(const romp_op& op1, const romp_op& op, const float* x,
     p.out_rs = op.out_rstride > 0 ? op.out_rstride : p.Wo * op.out_cstride;
     p.out_bs = op.out_bstride > 0 ? op.out_bstride : p.Ho * p.Wo * op.out_cstride;
     const int cap = conv_wg_cap();
-    long grid = (long)num_cu * ((cap > 0 && cap < X::WG_PER_CU) ? cap : X::WG_PER_CU);
-    if (grid > p.tiles_total) grid = p.tiles_total;
+    const long grid_max = (long)num_cu * ((cap > 0 && cap < X::WG_PER_CU) ? cap : X::WG_PER_CU);
+    // The strip form (RCfg): runs of L vertically consecutive tiles, L a divisor of the tile rows.  In units of one plain tile a
+    // carrying tile costs ~0.85 and a run's first ~1.05 (the prologue is not hand-scheduled); a workgroup takes ceil(runs / grid) runs
+    // against ceil(tiles / grid) plain tiles: the cheapest estimate wins, the plain kernel if none beats it (small batches: L = 1)
+    int L = 0;
+    {
+        auto rounds = [&](long items) { const long g = items < grid_max ? items : grid_max; return (items + g - 1) / g; };
+        double best = (double)rounds(p.tiles_total);
+        for (int l = 2; l <= p.tiles_y; ++l) {
+            if (p.tiles_y % l) continue;
+            const double c = (double)rounds(p.tiles_total / l) * (1.05 + 0.85 * (l - 1));
+            if (c < best - 1e-9) { best = c; L = l; }
+        }
+        // env ROMP_BBLOCK_RUN (tests, A/B runs; read at every launch -- launches are captured into the net's graph once): 0 = never the
+        // strip form, n > 1 = runs of n tiles wherever n divides the tile rows (the plain kernel elsewhere)
+        const char* e = getenv(C == 64 ? "ROMP_BBLOCK_RUN64" : "ROMP_BBLOCK_RUN32");       // (one channel count only: A/B runs)
+        if (!e) e = getenv("ROMP_BBLOCK_RUN");
+        const int run_env = e ? atoi(e) : -1;
+        if (run_env == 0) L = 0;
+        else if (run_env > 0) L = (run_env > 1 && p.tiles_y % run_env == 0) ? run_env : 0;
+    }
+    KernelFn f = fn;
+    long items = p.tiles_total;
+    if (L > 1 && fn == bblockr_kernel<C, 0>) {                 // (knock-out builds time the plain kernel)
+        f = fn_strip;
+        p.run_len = L;
+        items = p.tiles_total / L;
+        p.n_queues = (items % 8 == 0) ? 8 : 1;
+        p.per_queue = (int)(items / p.n_queues);
+    }
+    long grid = grid_max;
+    if (grid > items) grid = items;
     if (p.n_queues == 8) grid = grid >= 8 ? (grid / 8) * 8 : 8;
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
+    hipLaunchKernelGGL(f, dim3((unsigned)grid), dim3(256), X::LDS_BYTES, st, p);
     ROMP_HIP_CHECK(hipGetLastError());
     return ROMP_OK;
 }

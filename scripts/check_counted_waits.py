@@ -5,7 +5,7 @@ loads and stores; this script compiles the kernels to assembly and counts.
 
   seam1x1_kernel<0> (csrc/conv_h2x.hip): vmcnt(52) -- 16 t stores + 32 residual loads + 4 u stores after the m DMA of the next tile
   seam1x1_kernel<1>:                     vmcnt(20) -- 16 + 4 stores after the m and x0 DMAs
-  bblockr_kernel<64, 0> / <32, 0> (csrc/conv_h2c.h): vmcnt(6) / vmcnt(3) -- the output-row stores younger than the last halo piece
+  bblockr_kernel<64, 0, *> / <32, 0, *> (csrc/conv_h2c.h, plain and strip form): vmcnt(6) / vmcnt(3) -- the output-row stores younger than the last halo piece
 
 usage: python scripts/check_counted_waits.py [h2x] [h2c] [h2c32]     (default: h2x; h2c / h2c32 take about a minute each)
 Exit status 0 iff every counted wait found is covered."""
@@ -20,7 +20,8 @@ CSRC = os.path.join(ROOT, 'romp_amd', 'csrc')
 FILES = {'h2x': ('conv_h2x.hip', []), 'h2c': ('conv_h2c.hip', ['-mllvm', '-pragma-unroll-threshold=1000000']),
          'h2c32': ('conv_h2c32.hip', ['-mllvm', '-pragma-unroll-threshold=1000000'])}
 EXPECT = {'seam1x1_kernelILi0ELi0E': (52, 'loop'), 'seam1x1_kernelILi1ELi0E': (20, 'loop'),
-          'bblockr_kernelILi64ELi0E': (6, 'layout'), 'bblockr_kernelILi32ELi0E': (3, 'layout'),
+          'bblockr_kernelILi64ELi0ELb0E': (6, 'layout'), 'bblockr_kernelILi32ELi0ELb0E': (3, 'layout'),
+          'bblockr_kernelILi64ELi0ELb1E': (6, 'layout'), 'bblockr_kernelILi32ELi0ELb1E': (3, 'layout'),       # (the halo-carrying form: conv2 and its DMA schedule are the plain form's)
           }
 VMEM = re.compile(r'^\s*(global_load|global_store|buffer_load|buffer_store|global_atomic|buffer_atomic|flat_load|flat_store|scratch_)')
 
