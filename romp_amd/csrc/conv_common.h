@@ -56,6 +56,20 @@ struct ConvParams {
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// The arguments a conv kernel's set-up reads -- pointers, geometry, the work split -- asked for in ONE scalar-memory round trip at the
+// kernel's first instruction.  hipcc loads a by-value argument where its first use is: the kernels' set-up (early exit, item decode,
+// DMA tables, first stage) then runs 4-8 DEPENDENT s_load / s_waitcnt rounds of ~0.3-0.5 us in front of the first memory request
+// (round 6: profiles/r06s_trace3.txt, r06s_args_ab.txt).  An empty asm that names the fields as SGPR inputs pins their loads here, in
+// one clause under one wait; a field a kernel does not use costs it one more dword of that clause.  -DROMP_NO_ARGS_BATCH: the A/B build.
+__device__ __forceinline__ void conv_args_now(const ConvParams& p) {
+#ifndef ROMP_NO_ARGS_BATCH
+    asm volatile("" :: "s"(p.in), "s"(p.out), "s"(p.res), "s"(p.wh), "s"(p.scale_h), "s"(p.shift), "s"(p.zero), "s"(p.queue), "s"(p.trace),
+                 "s"(p.H), "s"(p.W), "s"(p.Ho), "s"(p.Wo), "s"(p.Cout), "s"(p.cin_valid), "s"(p.cin_pad), "s"(p.cout_pad),
+                 "s"(p.in_cs), "s"(p.in_co), "s"(p.in_gs), "s"(p.tiles_x), "s"(p.tiles_y), "s"(p.tiles_total), "s"(p.nslices), "s"(p.ns_total),
+                 "s"(p.n_queues), "s"(p.per_queue), "s"(p.pad_h), "s"(p.pad_w), "s"(p.dbg), "s"(gridDim.x));
+#endif
+}
+
 // ---- the H2 activation format -------------------------------------------------------------------------------------
 // An activation tensor the f16x2 kernels consume can live in HBM already split: per pixel and channel OCTET o (channels
 // 8o..8o+7) one 16-byte unit with the eight HIGH fp16 pieces h1 followed by one with the eight LOW pieces h2, where

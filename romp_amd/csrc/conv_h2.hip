@@ -5,6 +5,7 @@ namespace romp {
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;                            // ablation: launch cost only
     conv_split_body<2, KS, S, MT, NT, TW, CK>(p);
 }
@@ -12,6 +13,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_kernel(ConvParams p) {
 // the smallest tiles again, register budget of four workgroups per CU (128 VGPRs; <3,1,1,1,16,16> spills 7 dwords, the 1x1 none)
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256, 4) void conv_h2o4_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;
     conv_split_body<2, KS, S, MT, NT, TW, CK>(p);
 }

@@ -87,6 +87,25 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wv % X::NCG, tg = wv / X::NCG;              // this wave's channel group and row group
     const int px = lane & 15, q = lane >> 4;                   // B / D operand: pixel px of the block; A: channel px; k-quarter (D: channel quad) q
+    // Every kernel argument the set-up reads, asked for in ONE scalar-memory round trip (hipcc otherwise loads each where its first
+    // use is: five dependent s_load / s_waitcnt rounds in front of the first memory request), and this wave's weights -- the longest
+    // transfer of the set-up, 72 / 36 KB -- requested at once, before the table arithmetic and the first halo: a wave's entry -> first
+    // DMA took 3.5 us and the weights another 3.9 us behind it (profiles/r06s_trace3.txt).
+    // Weights: 16 output channels x C input channels x 9 taps x 2 pieces of each conv.
+    asm volatile("" :: "s"(p.trace), "s"(p.w3), "s"(p.wh), "s"(p.n_queues), "s"(p.per_queue), "s"(p.run_len), "s"(p.tiles_x), "s"(p.tiles_y),
+                 "s"(p.H), "s"(p.W), "s"(p.Ho), "s"(p.Wo), "s"(p.in_cs), "s"(p.in), "s"(p.in_co), "s"(p.in_bytes), "s"(p.scale), "s"(p.w),
+                 "s"(p.scale_h), "s"(p.shift), "s"(p.act_scale));
+    frag w1[9][X::NKC][2], w2[9][X::NKC][2];                   // [tap][k-chunk of 32 input channels][piece]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kc = 0; kc < X::NKC; ++kc)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                w1[tap][kc][pc] = __builtin_bit_cast(frag, p.w3[(((cg * 9 + tap) * X::NKC + kc) * 2 + pc) * 64 + lane]);
+                w2[tap][kc][pc] = __builtin_bit_cast(frag, p.wh[(((cg * 9 + tap) * X::NKC + kc) * 2 + pc) * 64 + lane]);
+            }
+    asm volatile("" ::: "memory");
     int tr_n = 0;                                              // phase stamps (ROMP_CONV_TRACE=1): 1 entry, 4 set-up done, per tile 11 conv1 MFMAs,
     constexpr int tr_wpw = 4;                                  // 13 last hand-over, 12 barrier, 17 conv2 MFMAs, 15 barrier
     ROMP_TRACE(1);
@@ -196,17 +215,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
     Item it = tile_of(0, 0, 0);
 #pragma unroll
     for (int kk = 0; kk < X::NI; ++kk) fetch_piece(it, true, false, true, kk);
-    // ---- this wave's weights (asked for AFTER the first halo: both trips overlap): 16 output channels x 64 input channels x 9 taps x 2 pieces of each conv
-    frag w1[9][X::NKC][2], w2[9][X::NKC][2];                   // [tap][k-chunk of 32 input channels][piece]
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int kc = 0; kc < X::NKC; ++kc)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                w1[tap][kc][pc] = __builtin_bit_cast(frag, p.w3[(((cg * 9 + tap) * X::NKC + kc) * 2 + pc) * 64 + lane]);
-                w2[tap][kc][pc] = __builtin_bit_cast(frag, p.wh[(((cg * 9 + tap) * X::NKC + kc) * 2 + pc) * 64 + lane]);
-            }
+    ROMP_TRACE(2);
     // a "use" of every weight register in front of the tile loop: hipcc waits for these loads HERE, once; the halo DMAs (invisible to
     // it) are covered by the explicit wait.  conv1's weights are pinned to AGPRs (MFMA reads them there), conv2's stay in VGPRs.
 #pragma unroll
@@ -214,6 +223,7 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #pragma unroll
         for (int kc = 0; kc < X::NKC; ++kc)
             asm volatile("" : "+a"(w1[tap][kc][0]), "+a"(w1[tap][kc][1]), "+v"(w2[tap][kc][0]), "+v"(w2[tap][kc][1]));
+    ROMP_TRACE(3);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     ROMP_TRACE(4);

@@ -5,6 +5,7 @@ namespace romp {
 
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256, 2) void conv_h2d_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;                            // ablation: launch cost only
     conv_splitd_body<2, KS, S, MT, NT, TW, CK>(p);
 }
@@ -12,6 +13,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2d_kernel(ConvParams p) {
 // one-block tiles again with the register budget of four workgroups per CU (115 / 123 VGPRs, no spill): more items in flight per CU
 template <int KS, int S, int MT, int NT, int TW, int CK>
 __global__ __launch_bounds__(256, 4) void conv_h2do4_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;
     conv_splitd_body<2, KS, S, MT, NT, TW, CK>(p);
 }

@@ -65,6 +65,7 @@ struct GStage {                 // wave-uniform description of one stage's sourc
 
 template <int KS, int P, int NS, int TW, int S, int KSUB>
 __global__ __launch_bounds__(256, 2) void conv_h2g_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;                            // ablation: launch cost only
     using X = GCfg<KS, P, NS, TW, S, KSUB>;
     using C = typename X::C;

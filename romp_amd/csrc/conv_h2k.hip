@@ -45,6 +45,7 @@ struct KStage {                 // wave-uniform description of one of this wave'
 
 template <int KS, int S, int P, int TW>
 __global__ __launch_bounds__(256, 2) void conv_h2k_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;
     using X = KCfg<KS, S, P, TW>;
     constexpr int TAPS = X::TAPS;

@@ -72,6 +72,7 @@ struct RStage {                 // wave-uniform description of one stage's sourc
 
 template <int P, int NS, int TW, int KSUB = 1>
 __global__ __launch_bounds__(256, 2) void conv_h2r_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;                            // ablation: launch cost only
     using X = RCfg<P, NS, TW, KSUB>;
     using C = typename X::C;

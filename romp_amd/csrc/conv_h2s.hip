@@ -56,6 +56,7 @@ struct SStage {                 // wave-uniform description of one stage's sourc
 
 template <int P, int NS, int TW>
 __global__ __launch_bounds__(256, 2) void conv_h2s_kernel(ConvParams p) {
+    conv_args_now(p);
     if (p.dbg & 32) return;                            // ablation: launch cost only
     using X = SCfg<P, NS, TW>;
     using C = typename X::C;

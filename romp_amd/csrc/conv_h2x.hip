@@ -47,6 +47,7 @@ typedef float f32x4x __attribute__((ext_vector_type(4)));
 
 template <int DS, int DRAIN = 0>
 __global__ __launch_bounds__(256, 1) void seam1x1_kernel(ConvParams p) {
+    conv_args_now(p);
     using X = XCfg;
     using frag = f16x8;
     extern __shared__ __attribute__((aligned(16))) float smem[];

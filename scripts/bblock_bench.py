@@ -26,7 +26,7 @@ def build(dev, H, fuse, Cc=32):
     return P, ops
 
 
-NAMES = {1: 'entry', 4: 'set-up', 11: 'conv1 units', 13: 'hand-over tail', 12: 'barrier A', 17: 'conv2 units', 14: 'finish tail', 15: 'barrier B'}
+NAMES = {1: 'entry', 2: 'tables + halo DMA issued', 3: 'weights landed', 4: 'set-up', 11: 'conv1 units', 13: 'hand-over tail', 12: 'barrier A', 17: 'conv2 units', 14: 'finish tail', 15: 'barrier B'}
 
 
 def trace_report(lib):
