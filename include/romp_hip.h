@@ -37,7 +37,7 @@ extern "C" {
 #define ROMP_ENOMEM     -3   /* workspace allocation failed                 */
 #define ROMP_ECAPACITY  -4   /* batch larger than the context was built for */
 
-#define ROMP_ABI_VERSION 6   /* 6: ROMP_OPF_SEAM_DS / unknown flag bits rejected, romp_net_plan_kind, romp_parse_watch, romp_net_sat_counter */
+#define ROMP_ABI_VERSION 7   /* 7: ROMP_OP_STEM7P;  6: ROMP_OPF_SEAM_DS / unknown flag bits rejected, romp_net_plan_kind, romp_parse_watch, romp_net_sat_counter */
 
 int         romp_abi_version(void);
 const char* romp_last_error(void);
@@ -104,6 +104,11 @@ const char* romp_last_error(void);
                                    (NOP, fields intact, in_buf = ROMP_BUF_IMAGE) is the ROMP_OP_STEM 3 -> 64 conv, this op the 3x3 stride-2
                                    64 -> 64 conv + BN + ReLU that read its output; the 64-channel half-resolution tensor between them
                                    is never written.  weight_aux = this conv's per-wave f16x2 pack (ROMP_OPF_WAVE16), H2 output        */
+#define ROMP_OP_STEM7P    20    /* ResNet-50's whole stem as one kernel (csrc/stem7p.hip, plan.fuse_stem7p; romp/lib/models/resnet_50.py:32-45,56):
+                                   normalisation + conv7x7 s2 p3 3 -> 64 + BN + ReLU + MaxPool2d(3, 2, 1) on the matrix cores.  The op itself
+                                   carries everything (H x W of the IMAGE, in_buf = ROMP_BUF_IMAGE, weight [ky][kx][ci][co] float32, scale,
+                                   shift; out_* the POOLED tensor, float32 or H2); the op before it is the NOP the ROMP_OP_STEM7 turned into:
+                                   the half-resolution 64-channel tensor between conv and pool is never written                         */
 /* ROMP_OP_CONV with ksize == 13 is a Conv1d(k=3) along W whose rows are the B batch items. */
 
 /* romp_op.flags */

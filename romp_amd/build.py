@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libromp_hip.so')
 # (heaviest translation units first: the thread pool below starts them in this order and the link waits for the slowest)
 SOURCES = ['conv_h2.hip', 'conv_h2c.hip', 'conv_h2c32.hip', 'conv_f32.hip', 'conv_h2d.hip', 'conv_h2b.hip', 'conv_h2r.hip',
-           'conv_h2s.hip', 'conv_mfma.hip', 'conv_h2k.hip', 'conv_h2g.hip', 'conv_h2x.hip', 'conv_fup.hip', 'stem_fuse.hip', 'stem2.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip',
+           'conv_h2s.hip', 'conv_mfma.hip', 'conv_h2k.hip', 'conv_h2g.hip', 'conv_h2x.hip', 'conv_fup.hip', 'stem_fuse.hip', 'stem2.hip', 'stem7p.hip', 'net.hip', 'parse.hip', 'smpl.hip', 'bev.hip',
            'post.hip', 'render.hip', 'temporal.hip']
 # optional: the bf16x3 family (`--conv_math bf16x3`; no committed variant table selects it; a minute of compile time): ROMP_WITH_BX3=1
 OPTIONAL_BX3 = 'conv_bx3.hip'

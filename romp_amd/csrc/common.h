@@ -57,6 +57,7 @@ int launch_stem(const romp_op& op, const float* image, float* out, int B, hipStr
 int launch_stem7(const romp_op& op, const float* image, float* out, int B, hipStream_t st);
 int launch_stem2(const romp_op& stem, const romp_op& op, const float* image, float* out, int B, hipStream_t st);   // stem2.hip (image == out == nullptr: set-up only)
 int launch_maxpool(const romp_op& op, const float* in, float* out, int B, hipStream_t st);
+int launch_stem7p(const romp_op& op, const float* image, float* out, int B, hipStream_t st);   // stem7p.hip (image == out == nullptr: set-up only)
 struct FuseTerm { const float* ptr; int shift; int cstride; int fmt; };
 int launch_fusesum(const FuseTerm* terms, int n_terms, float* out, int B, int H, int W, int C,
                    int out_cstride, int out_coff, int relu, hipStream_t st, int out_fmt = 0, int act_shift = 0);

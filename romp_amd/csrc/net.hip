@@ -111,6 +111,11 @@ static int run_op(romp_net* n, size_t idx, int variant, const float* image, int 
             ROMP_REQUIRE(in && out, "stem7: bad buffers %d -> %d", op.in_buf, op.out_buf);
             return launch_stem7(op, in, out, B, st);
         }
+        case ROMP_OP_STEM7P: {
+            float* out = resolve_out(n, op.out_buf, center, params);
+            ROMP_REQUIRE(image && out && op.in_buf == ROMP_BUF_IMAGE, "stem7p: bad buffers");
+            return launch_stem7p(op, image, out, B, st);
+        }
         case ROMP_OP_MAXPOOL: {
             const float* in = resolve_in(n, op.in_buf, image);
             float* out = resolve_out(n, op.out_buf, center, params);
@@ -459,6 +464,12 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
             if (rc) return rc;
             break;
         }
+    for (int i = 0; i < n_ops; ++i)
+        if (ops_host[i].kind == ROMP_OP_STEM7P) {
+            const int rc = launch_stem7p(ops_host[i], nullptr, nullptr, 0, nullptr);
+            if (rc) return rc;
+            break;
+        }
     for (int i = 0; i < n_ops; ++i)                            // (every instantiation in use: cheap, idempotent)
         if (ops_host[i].kind == ROMP_OP_FUSEUP) {
             const int rc = launch_fuseup(ops_host[i], nullptr, nullptr, 0, nullptr);
@@ -483,7 +494,7 @@ int romp_net_create(romp_net** out, const romp_op* ops_host, int n_ops, const in
     n->max_batch = max_batch;
     // graph replay launches op 0 eagerly and bakes no image pointer into the graph: only sound if nothing else reads the image
     n->image_only_in_op0 = n_ops > 0 && (n->ops[0].kind == ROMP_OP_STEM || n->ops[0].kind == ROMP_OP_STEM7);
-    if (n_ops > 1 && n->ops[0].kind == ROMP_OP_NOP && n->ops[0].in_buf == ROMP_BUF_IMAGE && n->ops[1].kind == ROMP_OP_STEM2) {
+    if (n_ops > 1 && n->ops[0].kind == ROMP_OP_NOP && n->ops[0].in_buf == ROMP_BUF_IMAGE && (n->ops[1].kind == ROMP_OP_STEM2 || n->ops[1].kind == ROMP_OP_STEM7P)) {
         n->image_only_in_op0 = true;                           // the fused stem: the NOP that holds the stem's fields + the kernel's op
         n->eager_ops = 2;
     }
@@ -821,6 +832,7 @@ static bool op_out_region(const romp_op& op, long long* npix, int* cs, int* coff
         case ROMP_OP_STEM: case ROMP_OP_STEM7: Ho = op.H / 2; Wo = op.W / 2; *C = op.Cout; break;
         case ROMP_OP_FUSESUM: case ROMP_OP_FUSEUP: case ROMP_OP_KSUM: case ROMP_OP_BBLOCK32: case ROMP_OP_BBLOCK64: case ROMP_OP_SEAM1X1: *C = op.Cout; break;
         case ROMP_OP_STEM2: Ho = op.H / 2; Wo = op.W / 2; *C = op.Cout; break;      // (H x W of the op: conv2's input size)
+        case ROMP_OP_STEM7P: Ho = op.H / 4; Wo = op.W / 4; *C = op.Cout; break;     // (H x W of the op: the image)
         default: return false;
     }
     *npix = (long long)Ho * Wo; *cs = op.out_cstride; *coff = op.out_coff;
@@ -978,6 +990,7 @@ int romp_conv_describe(const romp_op* op, int B, int variant, char* out, int n) 
     if (op->kind == ROMP_OP_BBLOCK32) { snprintf(out, n, "bblock32"); return ROMP_OK; }
     if (op->kind == ROMP_OP_BBLOCK64) { snprintf(out, n, "bblock64"); return ROMP_OK; }
     if (op->kind == ROMP_OP_STEM2) { snprintf(out, n, "stem2"); return ROMP_OK; }
+    if (op->kind == ROMP_OP_STEM7P) { snprintf(out, n, "stem7p"); return ROMP_OK; }
     if (op->kind == ROMP_OP_SEAM1X1) { snprintf(out, n, (op->flags & ROMP_OPF_SEAM_DS) ? "seam1x1_ds" : "seam1x1"); return ROMP_OK; }
     if (op->kind == ROMP_OP_FORK) { snprintf(out, n, "fork"); return ROMP_OK; }
     if (op->kind == ROMP_OP_JOIN) { snprintf(out, n, "join"); return ROMP_OK; }

@@ -10,13 +10,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ROMP_HIP_LIB') or os.path.join(_HERE, 'libromp_hip.so')     # (ROMP_HIP_LIB: a debug build of the same ABI)
 
-ABI_VERSION = 6          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
+ABI_VERSION = 7          # ROMP_ABI_VERSION of include/romp_hip.h this binding was written against
 BUF_NONE, BUF_IMAGE, BUF_CENTER, BUF_PARAMS = -1, -2, -3, -4
 FMT_F32, FMT_H2 = 0, 1
 OP_STEM, OP_CONV, OP_FUSESUM, OP_FORK, OP_JOIN, OP_BEV_PACK, OP_BEV_MAPS, OP_CONV3D = 1, 2, 3, 4, 5, 6, 7, 8
 OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, OP_FUSEUP, OP_RECORD, OP_WAIT = 12, 13, 14, 15, 16, 17, 18
 OP_KSUM = 11
 OP_STEM2 = 19
+OP_STEM7, OP_MAXPOOL, OP_STEM7P = 9, 10, 20
 OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS = 1, 2, 4
 
 

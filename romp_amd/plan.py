@@ -20,7 +20,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .lib import (OP_RECORD, OP_WAIT, OPF_WAVE16, OPF_STEM_VALU, OPF_SEAM_DS, OP_FUSEUP, OP_NOP, OP_BBLOCK32, OP_BBLOCK64, OP_SEAM1X1, BUF_CENTER, BUF_IMAGE, BUF_NONE, BUF_PARAMS, FMT_F32, FMT_H2, OP_BEV_MAPS, OP_CONV, OP_FORK,
-                  OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, OP_STEM2, RompOp)
+                  OP_FUSESUM, OP_JOIN, OP_KSUM, OP_STEM, OP_STEM2, OP_STEM7, OP_MAXPOOL, OP_STEM7P, RompOp)
 
 BN_EPS = 1e-5
 HEAD_IN_CH = 48          # 32 backbone + 2 CoordConv channels, zero-padded to a multiple of 16 (the f16x2 kernels' channel chunk:
@@ -228,6 +228,11 @@ def assign_formats(P):
             g['uses'].append((i, 'out'))
             g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
         elif op.kind == OP_STEM:
+            g = gen_for_write(op.out_buf)
+            g['uses'].append((i, 'out'))
+            g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
+        elif op.kind == OP_MAXPOOL and _stem7p_pair(P, i):   # ResNet-50's stem + pool, about to become one MFMA kernel (fuse_stem7p): it writes either format
+            gen_for_read(op.in_buf)['ok'] = False
             g = gen_for_write(op.out_buf)
             g['uses'].append((i, 'out'))
             g['ok'] &= oct_ok(op.out_cstride, op.out_coff)
@@ -594,6 +599,51 @@ def fuse_basic_blocks(P):
     return P.fused_blocks
 
 
+def _stem7p_pair(P, i):
+    """ops[i - 1], ops[i] = ResNet-50's stem conv (MFMA-eligible) and the max-pool that is the only reader of its output?"""
+    import os
+    if not getattr(P, 'f16x2', False) or os.environ.get('ROMP_FUSE_STEM7P', '1') == '0' or i != 1:
+        return False
+    a, b = P.ops[0], P.ops[1]
+    if not (a.kind == OP_STEM7 and b.kind == OP_MAXPOOL and not (a.flags & OPF_STEM_VALU) and a.out_buf >= 0 and b.in_buf == a.out_buf and
+            b.in_cstride == a.out_cstride and a.out_coff == 0 and a.Cout == 64 and b.Cin == 64 and a.H % 32 == 0 and a.W % 32 == 0 and
+            (b.H, b.W) == (a.H // 2, a.W // 2) and a.stream == b.stream and b.out_buf >= 0 and (b.out_cstride & 3) == 0):
+        return False
+    for j in range(2, len(P.ops)):                               # the conv's output must die in the pool
+        o = P.ops[j]
+        if o.kind in (OP_FORK, OP_JOIN, OP_RECORD, OP_WAIT):
+            continue
+        reads = [o.in_buf, o.res_buf] + [o.term_buf[k] for k in range(o.n_terms if o.kind in (OP_FUSESUM, OP_FUSEUP) else 0)]
+        if a.out_buf in reads:
+            return False
+        if o.out_buf == a.out_buf and o.kind != OP_NOP:
+            break
+    return True
+
+
+def fuse_stem7p(P):
+    """Peephole (after assign_formats): ResNet-50's stem -- ROMP_OP_STEM7 (normalisation + conv7x7 s2 + BN + ReLU) followed by
+    ROMP_OP_MAXPOOL (romp/lib/models/resnet_50.py:32-45,56) -- becomes ONE launch on the matrix cores (csrc/stem7p.hip): the conv's op
+    turns into ROMP_OP_NOP, the pool's into ROMP_OP_STEM7P carrying the conv's fields and its own output (float32 or H2, as the format
+    pass decided).  The 64-channel half-resolution tensor (16.8 MB per image) is never written or read.  f16x2 programs only (the
+    float32 / calibration programs keep the exact VALU conv), weights within the fp16 pieces (ROMP_OPF_STEM_VALU otherwise, set by
+    resnet_plan._stem7; env ROMP_STEM=valu forces it), env ROMP_FUSE_STEM7P=0: off (A/B runs).  -> 1 if fused."""
+    P.fused_stem7p = 0
+    if len(P.ops) < 2 or not _stem7p_pair(P, 1):
+        return 0
+    a, b = P.ops[0], P.ops[1]
+    b.weight, b.scale, b.shift = a.weight, a.scale, a.shift
+    b.H, b.W, b.Cin, b.Cout, b.ksize, b.stride, b.relu, b.groups = a.H, a.W, 3, 64, 7, 2, 1, 1
+    b.in_buf, b.in_cstride, b.in_coff = BUF_IMAGE, 3, 0
+    a.kind, b.kind = OP_NOP, OP_STEM7P
+    P.flops[1] += P.flops[0]
+    P.flops[0] = 0.0
+    P.bytes[1] = 4.0 * (a.H * a.W * 3 + (a.H // 4) * (a.W // 4) * 64)        # the image in, the pooled tensor out
+    P.bytes[0] = 0.0
+    P.fused_stem7p = 1
+    return 1
+
+
 def fuse_stem2(P):
     """Peephole (after assign_formats): HRNet's stem -- ROMP_OP_STEM 3 -> 64 (MFMA form, H2 output) followed by the 3x3 stride-2
     64 -> 64 conv + BN + ReLU that is the only reader of its output (model.py:384-390) -- becomes ONE launch (csrc/stem2.hip): the
@@ -929,6 +979,7 @@ class Program:
         if not getattr(self, '_lowered', False):
             assign_formats(self)
             fuse_stem2(self)                 # (first: its reader analysis wants every op still a plain conv)
+            fuse_stem7p(self)
             fuse_basic_blocks(self)
             fuse_bottleneck_seams(self)
             fuse_up_sums(self)

@@ -13,7 +13,7 @@ romp/lib/models/basic_modules.py Bottleneck :90-128, romp/lib/models/romp_model.
 """
 import torch
 
-from .lib import RompOp
+from .lib import RompOp, OPF_STEM_VALU
 from .plan import Act, Program, build_romp_head, fold_bn, _clean, set_conv_math, BUF_IMAGE, BUF_NONE
 
 OP_STEM7, OP_MAXPOOL = 9, 10
@@ -30,6 +30,12 @@ def _stem7(P: Program, name, w, scale, shift, H, W):
     op.H, op.W, op.Cin, op.Cout, op.ksize, op.stride, op.relu, op.groups = H, W, 3, 64, 7, 2, 1, 1
     op.in_cstride, op.out_cstride = 3, 64
     op.weight, op.scale, op.shift = pw.data_ptr(), ps.data_ptr(), pb.data_ptr()
+    # the MFMA form (plan.fuse_stem7p: conv + pool as one kernel) splits 256 w into fp16 pieces: a weight beyond +-255.9 would be clamped
+    # -> the exact float32 VALU kernel + the pool for such a checkpoint; env ROMP_STEM=valu forces it (A/B runs, tests)
+    import os
+    wmax = float(w.abs().max()) if w.numel() else 0.0
+    if os.environ.get('ROMP_STEM', '') == 'valu' or not (wmax * 256.0 < 65504.0):
+        op.flags |= OPF_STEM_VALU
     P.ops.append(op); P.names.append(name)
     P.flops.append(2.0 * (H // 2) * (W // 2) * 64 * 147)
     P.bytes.append(4.0 * (H * W * 3 + (H // 2) * (W // 2) * 64))

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(h, n), 'libromp_hip.so does not export %s' % n
     assert set(names) == set(L.EXPORTS), set(names) ^ set(L.EXPORTS)
-    assert h.romp_abi_version() == L.ABI_VERSION == 6
+    assert h.romp_abi_version() == L.ABI_VERSION == 7
 
 
 def test_romp_op_struct_layout_matches_header():

@@ -29,6 +29,70 @@ def _variants(lib, op, B):
     return [(0, v) for v in range(lib.romp_conv_num_variants()) if lib.romp_conv_describe(C.byref(op), B, v, buf, 128) == 0]
 
 
+@pytest.mark.parametrize('B,S,fmt', [(1, 64, 'h2'), (3, 96, 'h2'), (2, 128, 'f32'), (2, 512, 'h2'), (5, 160, 'f32')])
+def test_stem7p_vs_torch(dev, B, S, fmt, monkeypatch):
+    """csrc/stem7p.hip (ROMP_OP_STEM7P): ImageNet normalisation + conv7x7 s2 p3 + BN + ReLU + MaxPool2d(3, 2, 1) as ONE MFMA kernel
+    (romp/lib/models/resnet_50.py:32-45,56), lowered by plan.fuse_stem7p from the [STEM7, MAXPOOL] pair, against torch on the CPU:
+    image borders on every side (the conv's zero padding after normalisation, the pool's -inf padding), partial last workgroup
+    rounds, both output formats."""
+    from romp_amd import lib as L
+    from romp_amd.plan import Program, set_conv_math, decode_h2
+    from romp_amd.resnet_plan import _stem7, _maxpool
+    monkeypatch.delenv('ROMP_STEM', raising=False)
+    g = torch.Generator().manual_seed(10 * S + B)
+    img = torch.randint(0, 256, (B, S, S, 3), generator=g).float()
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.08
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    x = ((img / 255.0 - mean) / std).permute(0, 3, 1, 2)
+    m = torch.relu(F.conv2d(x, w, None, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref = F.max_pool2d(m, 3, 2, 1).permute(0, 2, 3, 1)
+    P = Program(dev)
+    set_conv_math(P, 'f16x2')
+    y = _maxpool(P, 'pool', _stem7(P, 'stem', w, sc, sh, S, S))
+    if fmt == 'f32':
+        P.exported_bufs.add(y.buf)                           # a tensor the host reads stays float32
+    ops = P.op_array()
+    assert P.fused_stem7p == 1 and [o.kind for o in P.ops] == [L.OP_NOP, L.OP_STEM7P]
+    assert P.ops[1].out_fmt == (L.FMT_H2 if fmt == 'h2' else L.FMT_F32)
+    lib = L.load()
+    h = C.c_void_p()
+    sizes = (C.c_int64 * len(P.buf_floats))(*P.buf_floats)
+    L.check(lib.romp_net_create(C.byref(h), ops, len(P.ops), sizes, len(P.buf_floats), B))
+    try:
+        xd = img.to(dev).contiguous()
+        dummy = torch.empty(16, device=dev)
+        n = P.buf_floats[y.buf] * B
+        out = torch.empty(n, device=dev)
+        for rep in range(2):
+            L.check(lib.romp_net_forward(h, L.ptr(xd), B, L.ptr(dummy), L.ptr(dummy), L.stream_ptr(dev)))
+            L.check(lib.romp_net_read_buffer(h, y.buf, B, L.ptr(out), n, L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            got = out.cpu().reshape(B, S // 4, S // 4, 64)
+            if fmt == 'h2':
+                got = decode_h2(got)
+            err = (got - ref).abs().max().item() / ref.abs().max().item()
+            print(f'stem7p B={B} {S}x{S} {fmt} run {rep}: relative err {err:.3e}')
+            assert err < 2e-5, err
+    finally:
+        lib.romp_net_destroy(h)
+
+
+def test_stem7p_falls_back_to_the_float32_pair(dev, monkeypatch):
+    """ROMP_STEM=valu (and weights beyond the fp16 pieces): the plan keeps ROMP_OP_STEM7 + ROMP_OP_MAXPOOL."""
+    from romp_amd.plan import Program, set_conv_math
+    from romp_amd.resnet_plan import _stem7, _maxpool, OP_STEM7, OP_MAXPOOL
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(64, 3, 7, 7, generator=g)
+    for env, scale in (('valu', 0.05), ('', 300.0)):
+        monkeypatch.setenv('ROMP_STEM', env)
+        P = Program(dev)
+        set_conv_math(P, 'f16x2')
+        _maxpool(P, 'pool', _stem7(P, 'stem', w * scale, torch.ones(64), torch.zeros(64), 64, 64))
+        P.op_array()
+        assert P.fused_stem7p == 0 and [o.kind for o in P.ops] == [OP_STEM7, OP_MAXPOOL]
+
+
 @pytest.mark.parametrize('cin,cout,H', [(2048, 256, 16), (256, 128, 32), (128, 64, 64)])
 def test_transposed_conv_as_parity_convs(dev, cin, cout, H):
     """ConvTranspose2d(k4, s2, p1) + BN + ReLU (resnet_50.py:93-120) == four 2x2 convs writing interleaved."""
