@@ -377,6 +377,9 @@ def test_every_conv_has_a_kernel_for_its_formats(model):
             written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM:
             written[op.out_buf] = op.out_fmt
+        elif op.kind == L.OP_STEM7P:                          # ResNet-50's fused stem + pool (round 6): reads the image, writes the pooled tensor
+            assert P.ops[0].kind == L.OP_NOP and op is P.ops[1] and op.in_buf == L.BUF_IMAGE and op.ksize == 7 and op.weight, name
+            written[op.out_buf] = op.out_fmt
         elif op.kind == L.OP_STEM2:                           # the fused stem (round 6): reads the image, writes y in H2
             assert op.out_fmt == L.FMT_H2 and (op.flags & L.OPF_WAVE16) and op.weight_aux and P.ops[0].kind == L.OP_NOP and op is P.ops[1], name
             n_h2 += 1
