@@ -8,8 +8,9 @@
 //   * K = 147 = 7 rows x 21 (dx, colour) values runs as FIVE 32-wide f16x2 MFMA steps (v_mfma_f32_16x16x32_f16, the three piece
 //     products hi*lo + lo*hi + hi*hi, float32 accumulate -- every other conv's arithmetic): a kernel row is padded to 22 so that an fp16
 //     PAIR never straddles two rows, k' = 22 dy + 3 dx + c, 154 of 160 slots used (zero weights elsewhere);
-//   * the normalised image halo of a tile sits in LDS ALREADY SPLIT -- a plane of high and a plane of low fp16 pieces of 16 x, rows 118
-//     halves apart (even: pairs stay 4-byte aligned) -- so the im2col gather of a pixel is 40 ds_read_b32 and no conversion work;
+//   * the normalised image halo of a tile sits in LDS ALREADY SPLIT into the high and low fp16 pieces of 16 x, in 8-byte units of two
+//     values (hi0 hi1 lo0 lo1), rows 118 values apart: the im2col gather of a pixel is 20 aligned ds_read_b64 -- each the high AND the
+//     low pair of one MFMA operand dword -- and no conversion work (a pixel's taps start 6 values = 24 bytes behind its neighbour's);
 //   * wave g owns output channels 16 g .. 16 g + 15 (A operand: 5 steps x 2 pieces = 40 registers, formed once per workgroup from the
 //     float32 weights x 256) and walks ALL pixels of the tile's m region, two 16-pixel blocks in flight (independent accumulators);
 //   * a tile is 4 x 8 pooled pixels = 9 x 17 pixels of m (153 = 10 blocks; 1.25 x recompute for the pool's halo): BN + ReLU in float32,
@@ -19,6 +20,10 @@
 //   * persistent workgroups (two per CU), the next tile's raw image values fetched into registers under the MFMAs and normalised /
 //     split / written to the second halo buffer before the tile's one barrier.
 // The float32 VALU pair stays for the float32 / calibration programs and whenever 256 |w| would leave the fp16 pieces (plan side).
+// Measured (B = 32, per-op HIP events, profiles/r06s_stem7p*_ab.txt): 0.53 + 0.15 ms as two launches -> 0.315 ms (first form: piece planes,
+// 40 ds_read_b32 per block) -> 0.278 ms (this form); 141-145 TFLOP/s algorithmic.  The kernel is latency-bound at two waves per SIMD
+// (~1 500 instructions per wave and tile in ~18 000 clocks): neither the DS instruction count (halved: -12 %) nor the VALU count
+// (-40 %: reciprocal normalisation, per-thread slot tables) nor unrolling the block loop moved it further.
 #include "conv_common.h"
 #include "conv_split.h"
 #include "conv_fuse.h"
@@ -44,11 +49,12 @@ struct S7Cfg {
     static constexpr int NBLK = (NPIX + 15) / 16;              // 10 blocks of 16
     static constexpr int IR = 2 * MR + 5, IC = 2 * MC + 5;     // 23 x 39 image pixels
     static constexpr int RS = 118;                             // halves per halo row: 117 values + 1 (even: aligned pairs)
-    static constexpr int PLANE = (IR + 1) * RS + 8;            // one piece plane: a zero row behind the last (k' rows 7 of the bottom pixels) + slack
+    static constexpr int PLANE = (IR + 1) * RS + 8;            // values of a halo buffer: a zero row behind the last (k' rows 7 of the bottom pixels) + slack
+    static constexpr int BUF_BYTES = PLANE * 4;                // a value = its high and its low fp16 piece, in 8-byte units of two values: hi0 hi1 lo0 lo1
     static constexpr int NVAL = IR * IC * 3;                   // 2 691 values per tile
     static constexpr int NL = (NVAL + 255) / 256;              // 11 loads per thread
     static constexpr int KROW = 22, NSTEP = 5;                 // k' = 22 dy + 3 dx + c; 5 x 32 >= 7 x 22
-    static constexpr int OFF_P = 2 * 2 * PLANE * 2;            // two halo buffers x {high, low} x 2 bytes
+    static constexpr int OFF_P = 2 * BUF_BYTES;                // two halo buffers
     static constexpr int PARK = NBLK * 16 * 16 * 4;            // per wave: 160 pixels x 16 channels float32
     static constexpr int LDS_BYTES = OFF_P + 4 * PARK;         // 22 720 + 40 960
     static_assert(OFF_P % 16 == 0 && PLANE % 2 == 0, "alignment");
@@ -64,7 +70,6 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(Stem7pParams p) {
     typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sBuf = reinterpret_cast<char*>(smem);
-    _Float16* sH = reinterpret_cast<_Float16*>(sBuf);          // buffer b: high plane at (2 b) * PLANE, low plane at (2 b + 1) * PLANE
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, q = lane >> 4;
@@ -82,6 +87,13 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(Stem7pParams p) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     float raw[X::NL];
     unsigned okm = 0u;
+    int slot[X::NL];                                           // this thread's values of a tile, the same for every tile: halo row | column << 5 | colour << 11 | LDS half index << 13
+#pragma unroll
+    for (int k = 0; k < X::NL; ++k) {
+        const int idx = tid + k * 256 < X::NVAL ? tid + k * 256 : 0;
+        const int hy = idx / (X::IC * 3), e = idx % (X::IC * 3);
+        slot[k] = hy | ((e / 3) << 5) | ((e % 3) << 11) | ((hy * X::RS + e) << 13);
+    }
     auto tile_of = [&](int t, int& b, int& ty, int& tx) __attribute__((always_inline)) {
         tx = t % p.tiles_x; t /= p.tiles_x;
         ty = t % p.tiles_y;
@@ -95,41 +107,44 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(Stem7pParams p) {
         okm = 0u;
 #pragma unroll
         for (int k = 0; k < X::NL; ++k) {
-            const int idx = tid + k * 256;
-            const int idc = idx < X::NVAL ? idx : 0;
-            const int hy = idc / (X::IC * 3), e = idc % (X::IC * 3);
-            const int iy = iy0 + hy, ix = ix0 + e / 3;
-            const bool ok = idx < X::NVAL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int hy = slot[k] & 31, col = (slot[k] >> 5) & 63, c = (slot[k] >> 11) & 3;
+            const int iy = iy0 + hy, ix = ix0 + col;
+            const bool ok = tid + k * 256 < X::NVAL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             okm |= ok ? 1u << k : 0u;
-            raw[k] = img[ok ? ((size_t)iy * p.W + ix0) * 3 + e : 0];
+            raw[k] = img[ok ? (unsigned)((iy * p.W + ix) * 3 + c) : 0u];       // (unsigned: a 32-bit offset from the image's scalar base)
         }
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
-        _Float16* hi = sH + (2 * buf) * X::PLANE;
-        _Float16* lo = hi + X::PLANE;
+        _Float16* hv = reinterpret_cast<_Float16*>(sBuf + buf * X::BUF_BYTES);   // value v: high piece at half 4 (v / 2) + (v & 1), low piece 2 halves on
 #pragma unroll
         for (int k = 0; k < X::NL; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < X::NVAL) {
-                const int hy = idx / (X::IC * 3), e = idx % (X::IC * 3);
-                const int c = e % 3;
-                // (the reference's float32 normalisation, then x 16 -- exact -- the fp16 pieces' scale; zero padding AFTER normalisation)
-                const float v = ((okm >> k) & 1u) ? ((raw[k] / 255.0f - mean[c]) / stdv[c]) * 16.0f : 0.f;
+            if (tid + k * 256 < X::NVAL) {
+                const int c = (slot[k] >> 11) & 3, at = (unsigned)slot[k] >> 13;
+                const float mc = c == 0 ? mean[0] : c == 1 ? mean[1] : mean[2], rs = c == 0 ? 16.0f / stdv[0] : c == 1 ? 16.0f / stdv[1] : 16.0f / stdv[2];
+                // (x / 255 - mean) / std as the reference normalises (resnet_50.py:41-44), with reciprocal multiplies: within an ulp of
+                // its two divisions -- below the 2^-22 of the split that follows; 22 IEEE divisions per thread and tile were a quarter of
+                // the kernel's VALU work -- times 16, the fp16 pieces' scale; zero padding AFTER normalisation
+                const float v = ((okm >> k) & 1u) ? (raw[k] * (1.0f / 255.0f) - mc) * rs : 0.f;
                 const _Float16 h = (_Float16)v;
-                hi[hy * X::RS + e] = h;
-                lo[hy * X::RS + e] = (_Float16)(v - (float)h);
+                hv[4 * (at >> 1) + (at & 1)] = h;
+                hv[4 * (at >> 1) + (at & 1) + 2] = (_Float16)(v - (float)h);
             }
         }
     };
 
-    // ---- this lane's 20 pair offsets (halves, relative to the pixel's first tap): pair jj of step s is k' = 32 s + 8 q + 2 jj
+    // ---- this lane's 20 pair offsets (values, relative to the pixel's first tap): pair jj of step s is k' = 32 s + 8 q + 2 jj.  A pair
+    // is ONE aligned ds_read_b64 -- {high pair, low pair} -- because the halo is stored in 8-byte units of two values
+    // (hi0 hi1 lo0 lo1) and every pair starts at an even value: a pixel's taps start 6 values = 24 bytes behind its neighbour's.
+    // (Measured on the way, profiles/r06s_stem7p2_ab.txt: piece PLANES read by ds_read_b32 -- 40 reads per block -- 0.315 ms, the kernel
+    // bound by its DS instruction count; rows of 24 = three 8-half groups on misaligned ds_read_b128 0.99 ms -- legal here, but lane
+    // by lane: 21 B/clk/CU, scripts/micro/lds_unaligned_tp.hip -- and on four b32 with immediate offsets 0.36 ms: a sixth K step.)
     int koff[X::NSTEP][4];
 #pragma unroll
     for (int s = 0; s < X::NSTEP; ++s)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int k = 32 * s + 8 * q + 2 * jj;
-            koff[s][jj] = (k / X::KROW) * X::RS + k % X::KROW;                  // (k' >= 154: the zero row / finite neighbours, zero weights)
+            koff[s][jj] = ((k / X::KROW) * X::RS + k % X::KROW) * 4;            // bytes (k' >= 154: the zero row / finite neighbours, zero weights)
         }
     // ---- and the A operands: channel 16 wave + px, the same k' (zero where k' is padding), 256 w split into fp16 pairs
     frag wa[X::NSTEP][2];
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(Stem7pParams p) {
     }
     // this lane's pixels of the m region, block by block: (row, column) packed, and the halo offset of their first tap
     int pbase[X::NBLK];                                        // halves: (2 ry * RS + 6 rx) | ry << 20 | rx << 25  (pixels beyond 152: pixel 152's)
+
 #pragma unroll
     for (int blk = 0; blk < X::NBLK; ++blk) {
         const int i = blk * 16 + px < X::NPIX ? blk * 16 + px : X::NPIX - 1;
@@ -183,37 +199,34 @@ __global__ __launch_bounds__(256, 2) void stem7p_kernel(Stem7pParams p) {
         int b, ty, tx;
         tile_of(t, b, ty, tx);
         const int my0 = 2 * ty * X::TH - 1, mx0 = 2 * tx * X::TW - 1;           // m pixel of region pixel (0, 0)
-        const _Float16* hiP = sH + (2 * buf) * X::PLANE;
-        const _Float16* loP = hiP + X::PLANE;
         // ---- A. the conv, two blocks of 16 m pixels at a time
-#pragma unroll 1
+#pragma unroll 1                                                // (fully unrolled: 0.278-0.292 ms against 0.274-0.283, same box)
         for (int bp = 0; bp < X::NBLK; bp += 2) {
             f32x4p acc[2] = {(f32x4p){0.f, 0.f, 0.f, 0.f}, (f32x4p){0.f, 0.f, 0.f, 0.f}};
             int pb[2] = {pbase[0], pbase[1]};                  // (the table is indexed by a run-time block pair of a rolled loop: selects, not scratch)
 #pragma unroll
             for (int k = 2; k < X::NBLK; k += 2)
                 if (k == bp) { pb[0] = pbase[k]; pb[1] = pbase[k + 1]; }
+            const char* hb[2];
 #pragma unroll
-            for (int s = 0; s < X::NSTEP; ++s) {
+            for (int u = 0; u < 2; ++u) hb[u] = sBuf + buf * X::BUF_BYTES + (pb[u] & 0xfffff) * 4;
+#pragma unroll
+            for (int st = 0; st < X::NSTEP; ++st) {
                 frag xh[2], xl[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int base = pb[u] & 0xfffff;
-                    unsigned h[4], l[4];
+                    uint2 t[4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        h[jj] = *reinterpret_cast<const unsigned*>(hiP + base + koff[s][jj]);
-                        l[jj] = *reinterpret_cast<const unsigned*>(loP + base + koff[s][jj]);
-                    }
-                    xh[u] = __builtin_bit_cast(frag, make_uint4(h[0], h[1], h[2], h[3]));
-                    xl[u] = __builtin_bit_cast(frag, make_uint4(l[0], l[1], l[2], l[3]));
+                    for (int jj = 0; jj < 4; ++jj) t[jj] = *reinterpret_cast<const uint2*>(hb[u] + koff[st][jj]);
+                    xh[u] = __builtin_bit_cast(frag, make_uint4(t[0].x, t[1].x, t[2].x, t[3].x));
+                    xl[u] = __builtin_bit_cast(frag, make_uint4(t[0].y, t[1].y, t[2].y, t[3].y));
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][1], xh[u], acc[u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[st][1], xh[u], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][0], xl[u], acc[u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[st][0], xl[u], acc[u], 0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][0], xh[u], acc[u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[st][0], xh[u], acc[u], 0, 0, 0);
             }
             // BN + ReLU, zero outside the map, parked: pixel i of the region at sP[i * 16 + 4 q ..]
 #pragma unroll

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tee gpurun_out/round_end_tests.log | tail -6
+timeout 1200 python -m pytest tests -m gpu -x -q --durations=12 2>&1 | tee gpurun_out/round_end_tests.log | tail -6
 if ! grep -q " passed" gpurun_out/round_end_tests.log || grep -q " failed" gpurun_out/round_end_tests.log; then
     timeout 900 python -m pytest tests -m gpu -q 2>&1 | tee gpurun_out/round_end_tests_all.log | tail -30
 fi
