@@ -141,7 +141,8 @@ def roofline_report(net, images, pmc_workload=None):
         roof.update(achieved=round(achieved, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(mfma_frac, 4))
     fused = name.startswith('bblock')          # the fused BasicBlock ops run csrc/conv_h2c.h's kernel in batch plans (16x16x32 MFMAs)
     if fused:
-        roof['kernel_symbol'] = 'romp::bblockr_kernel<%s, 0>' % name[len('bblock'):] + (' (single-image plans: romp::bblock32_kernel<0>)' if name == 'bblock32' else '')
+        roof['kernel_symbol'] = 'romp::bblockr_kernel<%s, 0, true> (the halo-carrying strip form; <%s, 0, false> where no run length pays)' % (name[len('bblock'):], name[len('bblock'):]) + \
+                                (' (single-image plans: romp::bblock32_kernel<0>)' if name == 'bblock32' else '')
     roof.update(traffic=None,
                 pipe=('%s MFMA %s, %d piece products per f32 product' % ('bf16' if bx3 else 'f16', '16x16x32' if fused else '32x32x16', products)) if (bx3 or h2) else 'f32 MFMA 32x32x2',
                 tflops=round(achieved, 2), mfma_peak_tflops=round(peak, 1), mfma_frac=round(mfma_frac, 4),

@@ -15,8 +15,8 @@ import re
 import sys
 from collections import defaultdict
 
-NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|fuseup_kernel|stem_conv_kernel|stem_mfma_kernel|stem2_kernel|stem7_conv_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
-FIRST = ('stem_conv_kernel', 'stem_mfma_kernel', 'stem2_kernel', 'stem7_conv_kernel')
+NET_KERNEL = re.compile(r'romp::(conv_\w+_kernel|bblock32_kernel|bblockr_kernel|seam1x1_kernel|fuseup_kernel|stem_conv_kernel|stem_mfma_kernel|stem2_kernel|stem7_conv_kernel|stem7p_kernel|fusesum_kernel|ksum_kernel|maxpool3s2_kernel|conv3d_kernel|bev_pack_kernel|bev_maps_kernel)')
+FIRST = ('stem_conv_kernel', 'stem_mfma_kernel', 'stem2_kernel', 'stem7_conv_kernel', 'stem7p_kernel')
 
 
 def kernel_of(variant_name):
@@ -30,6 +30,8 @@ def kernel_of(variant_name):
         return ('fuseup_kernel',)
     if variant_name == 'stem2':
         return ('stem2_kernel',)
+    if variant_name == 'stem7p':
+        return ('stem7p_kernel',)
     if variant_name == 'seam1x1_ds':
         return ('seam1x1_kernel<1',)
     m = re.match(r'conv_(mfma|pp|bx3|bxd|h2do|h2o|h2d|h2p|h2w|h2q|h2r|h2s|h2k|h2g|h2)_k(\d+)s(\d+)_mt(\d+)_nt(\d+)_tw(\d+)_ck(\d+)', variant_name)

@@ -371,7 +371,9 @@ def test_fused_basic_block(dev, B, H, Cc, impl, monkeypatch):
 @pytest.mark.parametrize('B,H,Cc,run', [(3, 64, 64, 2), (3, 64, 64, 4), (2, 64, 64, 8), (1, 16, 64, 2), (2, 48, 64, 3), (2, 48, 64, 6),
                                         (3, 64, 32, 2), (3, 64, 32, 4), (3, 64, 32, 8), (2, 128, 32, 16), (2, 48, 32, 3), (1, 32, 32, 4),
                                         # the production launches: B = 32, the run length the launcher picks itself (4 of 8 tile rows / 8 of 16)
-                                        (32, 64, 64, None), (32, 128, 32, None), (5, 64, 64, None), (24, 128, 32, None)])
+                                        (32, 64, 64, None), (32, 128, 32, None), (5, 64, 64, None), (24, 128, 32, None),
+                                        # more runs than workgroups (256 / 512): 2.5 / 1.25 runs per workgroup, the run counter moves on inside the tile loop
+                                        (40, 64, 64, 2), (20, 128, 32, 4)])
 def test_fused_basic_block_strip(dev, B, H, Cc, run, monkeypatch):
     """conv_h2c.h's halo-carrying form (bblockr_kernel<C, 0, true>): a workgroup walks RUNS of vertically consecutive tiles, every tile
     but a run's first takes rows 8, 9 of the previous tile's intermediate over as its rows 0, 1 instead of recomputing them.  Every run
