@@ -473,25 +473,31 @@ __global__ __launch_bounds__(256, RCfg<C>::WG_PER_CU) void bblockr_kernel(ConvPa
 #pragma unroll
                         for (int i = 0; i < 4; ++i) ap[r][pr][i] = 0.f;
                 }
-                frag xb[2][2];
+#ifdef ROMP_BBLOCK_PFP1                                        // (A/B build: one unit ahead at both channel counts, the first form)
+                constexpr int PFP = 1;
+#else
+                constexpr int PFP = C == 64 ? 2 : 1;            // units ahead (64 channels: one wave per SIMD, a unit can be 3 MFMAs = 48 clocks)
+#endif
+                frag xb[PFP + 1][2];
                 auto read_p = [&](int u) __attribute__((always_inline)) {
 #pragma unroll
                     for (int pc = 0; pc < 2; ++pc) {
                         if (u < NPR) {
                             const int Ri = u / (3 * X::NKC), dx = (u / X::NKC) % 3, kc = u % X::NKC;
-                            xb[u & 1][pc] = *reinterpret_cast<const frag*>(sBuf + xp + ((8 * kc + pc) * X::XPL + Ri * X::IC + dx) * 16);
+                            xb[u % (PFP + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + xp + ((8 * kc + pc) * X::XPL + Ri * X::IC + dx) * 16);
                         } else {
                             const int kc = (u - NPR) % X::NKC, tap = (u - NPR) / X::NKC;
-                            xb[u & 1][pc] = *reinterpret_cast<const frag*>(sBuf + xq + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
+                            xb[u % (PFP + 1)][pc] = *reinterpret_cast<const frag*>(sBuf + xq + ((8 * kc + pc) * X::XPL + (tap / 3) * X::IC + tap % 3) * 16);
                         }
                     }
                 };
-                read_p(0);
+#pragma unroll
+                for (int u = 0; u < PFP; ++u) read_p(u);
                 SIDE_PIN();
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
-                    if (u + 1 < NP) read_p(u + 1);
-                    const frag (&x)[2] = xb[u & 1];
+                    if (u + PFP < NP) read_p(u + PFP);
+                    const frag (&x)[2] = xb[u % (PFP + 1)];
 #pragma unroll
                     for (int pr = 0; pr < 3; ++pr) {
                         if (u < NPR) {
